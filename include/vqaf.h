@@ -1,0 +1,250 @@
+/*
+ * libvqafuse — C ABI of the MI355X (gfx950) kernels behind the VQA fusion hot path.
+ *
+ * The reference (hanleju/VQA) has no FFI: its boundary for this path is the Python
+ * nn.Module protocol of utils/fusion.py and the Opacus call sites in train.py.  Each
+ * entry point below names the reference lines whose arithmetic it replaces; the Python
+ * host layer in vqa_amd/ binds these symbols with ctypes and re-creates the reference's
+ * module interface on top of them.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative VQAF_E_* code otherwise; never throw, never exit;
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - tensors are dense row-major; the caller owns every buffer, workspaces included;
+ *     the library allocates nothing and keeps no state between calls;
+ *   - work is only enqueued on `stream` (a hipStream_t passed as void*); no entry point
+ *     synchronises with the host, so all of them may be captured into a HIP graph;
+ *   - `dtype` is the storage type of token / activation tensors (VQAF_F32 or VQAF_BF16);
+ *     accumulation is always f32;
+ *   - index tensors are int64 (torch.long), as torch.topk / torch.gather use.
+ */
+#ifndef VQAF_H_
+#define VQAF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQAF_VERSION 100 /* major*10000 + minor*100 + patch */
+
+enum vqaf_status {
+  VQAF_OK = 0,
+  VQAF_E_SHAPE = -1,  /* a size is zero/negative or outside what the kernels support */
+  VQAF_E_DTYPE = -2,  /* dtype code is not VQAF_F32 / VQAF_BF16 */
+  VQAF_E_ALIGN = -3,  /* a pointer or row pitch is not 16-byte aligned */
+  VQAF_E_LAUNCH = -4, /* the HIP runtime refused the launch (hipGetLastError != 0) */
+  VQAF_E_NULL = -5    /* a required pointer is NULL */
+};
+
+enum vqaf_dtype { VQAF_F32 = 0, VQAF_BF16 = 1 };
+
+enum vqaf_noise_kind { VQAF_NOISE_NONE = 0, VQAF_NOISE_GAUSSIAN = 1, VQAF_NOISE_UNIFORM = 2 };
+
+typedef void* vqaf_stream_t; /* hipStream_t */
+
+int vqaf_version(void);
+const char* vqaf_status_string(int status);
+
+/* ------------------------------------------------------------------------------------
+ * Token scoring (single-query multi-head attention weights, head-averaged).
+ * Replaces the `nn.MultiheadAttention(query=q_global[:,None], key=seq, value=seq)` calls
+ * whose OUTPUT is discarded and only the (B,1,N) weights are used:
+ *   utils/fusion.py:234-238 (text->vision), :243-247 (vision->text), :159-163 (Attention).
+ *
+ *   w[b,n] = (1/H) sum_h softmax_n( (Wq_h q_b + bq_h) . (Wk_h x_bn + bk_h) / sqrt(D/H) )
+ *
+ * The key bias contributes a per-(b,h) constant that cancels in the softmax, and the
+ * value / output projections never reach the weights, so the kernels evaluate
+ *   u[b,h,:] = Wk_h^T (Wq_h q_b + bq_h) / sqrt(D/H),   s[b,n,h] = x_bn . u[b,h,:]
+ * in one pass over the tokens.
+ * ------------------------------------------------------------------------------------ */
+
+/* u (B,H,D) f32  <-  q (B,D) `dtype`, in_proj_weight (3D,D) / in_proj_bias (3D) `w_dtype`.
+ * `qproj_ws` is a (B,D) f32 workspace. */
+int vqaf_fold_query(const void* q, const void* in_proj_weight, const void* in_proj_bias,
+                    int B, int D, int H, int dtype, int w_dtype, float* qproj_ws, float* u,
+                    vqaf_stream_t stream);
+
+/* s (B,N,H) f32  <-  seq (B,N,D) `dtype`, u (B,H,D) f32.  Raw per-head scaled scores. */
+int vqaf_head_scores(const void* seq, const float* u, int B, int N, int D, int H, int dtype,
+                     float* s, vqaf_stream_t stream);
+
+/* w (B,N) f32  <-  s (B,N,H) f32: softmax over n per head, then mean over heads. */
+int vqaf_attn_weights(const float* s, int B, int N, int H, float* w, vqaf_stream_t stream);
+
+/* Bytes of workspace vqaf_score needs (qproj + u + s), 256-byte aligned pieces. */
+size_t vqaf_score_workspace_bytes(int B, int N, int D, int H);
+
+/* The three steps above in one call: w (B,N) f32 <- q, seq, in_proj_{weight,bias}. */
+int vqaf_score(const void* q, const void* seq, const void* in_proj_weight,
+               const void* in_proj_bias, int B, int N, int D, int H, int dtype, int w_dtype,
+               void* workspace, size_t workspace_bytes, float* w, vqaf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Keep-index selection.  Replaces torch.topk(attn_weights, k) (utils/fusion.py:44) and
+ * torch.topk(attn_weights, N-k, largest=False) (:51).
+ *   top    (B,K)   int64: indices of the K largest weights, weight descending;
+ *   bottom (B,N-K) int64: indices of the N-K smallest, weight ascending (may be NULL).
+ * Order is total and deterministic: (weight desc, index asc); `bottom` is the tail of that
+ * same ranking reversed, so top and bottom always partition [0,N).  NaN ranks above +inf
+ * (as torch.topk does); -0.0 ties with +0.0.  1 <= K <= N <= 4096.
+ * ------------------------------------------------------------------------------------ */
+int vqaf_topk(const float* w, int B, int N, int K, int64_t* top, int64_t* bottom,
+              vqaf_stream_t stream);
+
+/* Adversarial index mixing, batched.  Replaces the per-sample Python loop
+ * utils/fusion.py:56-65:  top[b, pos[b,j]] = bottom[b, src[b,j]]  for j < k_adv.
+ * pos (B,k_adv) int64 holds distinct positions in [0,K); src (B,k_adv) int64 distinct
+ * positions in [0,R).  The caller skips the call when R < k_adv, as the reference does
+ * (:57).  Out-of-range pos/src entries are ignored. */
+int vqaf_adv_swap(int64_t* top, const int64_t* bottom, const int64_t* pos, const int64_t* src,
+                  int B, int K, int R, int k_adv, vqaf_stream_t stream);
+
+/* Same, drawing pos/src inside the kernel: per sample, the first k_adv entries of a uniform
+ * random permutation of [0,K) and of [0,R) (what randperm(k)[:k_adv] / randperm(R)[:k_adv]
+ * at utils/fusion.py:59,62 produce), from the counter-based generator keyed by
+ * rng_state = {seed, counter} (two uint64 in device memory; not modified).
+ * Optionally records the draws in pos_out/src_out (B,k_adv) int64 (NULL to skip). */
+int vqaf_adv_swap_random(int64_t* top, const int64_t* bottom, int B, int K, int R, int k_adv,
+                         const uint64_t* rng_state, int64_t* pos_out, int64_t* src_out,
+                         vqaf_stream_t stream);
+
+/* counter += delta on the device (stream-ordered; graph-capturable). */
+int vqaf_rng_advance(uint64_t* rng_state, uint64_t delta, vqaf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Gather + optional noise + "remaining mean" mix token.  Replaces
+ * utils/fusion.py:67-92 (gather, _add_privacy_noise, mask/scatter_/masked mean/cat):
+ *   out[b,j,:] = seq[b, idx[b,j], :] (+ noise)                         j < K
+ *   out[b,K,:] = alpha * sum_{n not in idx[b]} seq[b,n,:] / (R_b + 1e-10)   if alpha > 0
+ * where R_b = N - |set(idx[b])|.  out is (B, K+1, D) when alpha > 0, else (B, K, D).
+ * Gathered rows are bit-exact copies when no noise is added.  The mix token is summed in
+ * f32 in a fixed order (deterministic run to run).
+ * Noise: `noise` (B,K,D) f32 is added if non-NULL; else if noise_kind != NONE, N(0,scale)
+ * or U(-scale,scale) is generated in the kernel from rng_state {seed, counter}.
+ * out_dtype: storage type of out (VQAF_F32 is always allowed; VQAF_BF16 only with
+ * dtype == VQAF_BF16).  Indices outside [0,N) produce a zero row and are not masked.
+ * ------------------------------------------------------------------------------------ */
+int vqaf_gather_mix(const void* seq, const int64_t* idx, const float* noise, int noise_kind,
+                    float noise_scale, const uint64_t* rng_state, float alpha, int B, int N,
+                    int K, int D, int dtype, int out_dtype, void* out, vqaf_stream_t stream);
+
+/* Backward of vqaf_gather_mix w.r.t. seq (autograd of utils/fusion.py:67-92):
+ *   grad_seq[b,n,:] = sum_{j: idx[b,j]==n} grad_out[b,j,:]
+ *                   + [n not in idx[b]] * alpha/(R_b+1e-10) * grad_out[b,K,:]
+ * grad_out is (B,K+1,D) (or (B,K,D) when alpha <= 0) of `g_dtype`; grad_seq (B,N,D) of
+ * `dtype`. */
+int vqaf_gather_mix_bwd(const void* grad_out, const int64_t* idx, float alpha, int B, int N,
+                        int K, int D, int g_dtype, int dtype, void* grad_seq,
+                        vqaf_stream_t stream);
+
+/* Mean over the token axis written into a column block of the fused feature:
+ *   out[b, col0 + d] = (1/M) sum_j x[b,j,d];   x (B,M,D) `dtype`, out (B,ld_out) `out_dtype`.
+ * Replaces `.mean(dim=1)` + torch.cat at utils/fusion.py:253-254,274 (:170,182). */
+int vqaf_mean_pool(const void* x, int B, int M, int D, int dtype, void* out, int ld_out,
+                   int col0, int out_dtype, vqaf_stream_t stream);
+
+/* Backward of vqaf_mean_pool: grad_x[b,j,d] = grad_out[b, col0+d] / M. */
+int vqaf_mean_pool_bwd(const void* grad_out, int ld_out, int col0, int g_dtype, int B, int M,
+                       int D, int dtype, void* grad_x, vqaf_stream_t stream);
+
+/* Pruning branch of one modality with the pooled output only (the (B,K+1,D) tensor is
+ * never written):  out[b, col0+d] = mean_j PrivacyAwareTokenPruning(seq, idx)[b,j,d].
+ * Same arguments as vqaf_gather_mix; utils/fusion.py:240,253 (and :249,254). */
+int vqaf_gather_mix_pool(const void* seq, const int64_t* idx, const float* noise,
+                         int noise_kind, float noise_scale, const uint64_t* rng_state,
+                         float alpha, int B, int N, int K, int D, int dtype, void* out,
+                         int ld_out, int col0, int out_dtype, vqaf_stream_t stream);
+
+/* Backward of vqaf_gather_mix_pool w.r.t. seq. */
+int vqaf_gather_mix_pool_bwd(const void* grad_out, int ld_out, int col0, int g_dtype,
+                             const int64_t* idx, float alpha, int B, int N, int K, int D,
+                             int dtype, void* grad_seq, vqaf_stream_t stream);
+
+/* Small strided-batched f32 GEMM used for the per-head projections around the kernels
+ * above:  C[g][m][n] = alpha * sum_k A[g][m][k] * Bm[g][k][n] (+ bias[g][n]) (+ C if beta_one)
+ * with element strides (s_g, s_m/s_k, s_k/s_n).  A and Bm may be f32 or bf16; C is f32. */
+int vqaf_gemm_f32(const void* A, int a_dtype, long a_sg, long a_sm, long a_sk, const void* Bm,
+                  int b_dtype, long b_sg, long b_sk, long b_sn, const void* bias, int bias_dtype,
+                  long bias_sg, float* C, long c_sg, long c_sm, int G, int M, int N, int K,
+                  float alpha, int beta_one, vqaf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * DP-SGD step for the classifier.  The reference delegates this to Opacus 1.4.0
+ * (GradSampleModule hooks + DPOptimizer.clip_and_accumulate / add_noise / scale_grad),
+ * reached from loss.backward() and optimizer['classifier'].step() at utils/src.py:99,104
+ * and configured at train.py:124-153.  Per-sample gradients are never materialised:
+ * for a Linear on 2-D input g_i^W = b_i a_i^T, so ||g_i^W||^2 = ||a_i||^2 ||b_i||^2.
+ * ------------------------------------------------------------------------------------ */
+
+/* sq[b] (+)= ||a_b||^2 * ||g_b||^2 + (has_bias ? ||g_b||^2 : 0)
+ * a (B,In), g (B,Out) of `dtype`; sq (B) f32; accumulate != 0 adds to sq. */
+int vqaf_ghost_sqnorm_linear(const void* a, const void* g, int B, int In, int Out, int dtype,
+                             int has_bias, int accumulate, float* sq, vqaf_stream_t stream);
+
+/* Per-sample squared gradient norm of an affine normalisation layer (GroupNorm weight and
+ * bias): sq[b] (+)= sum_c (xhat[b,c] g[b,c])^2 + sum_c g[b,c]^2.  xhat, g (B,C). */
+int vqaf_ghost_sqnorm_affine(const void* xhat, const void* g, int B, int C, int dtype,
+                             int accumulate, float* sq, vqaf_stream_t stream);
+
+/* coef[b] = scale * min(1, max_norm / (scale*sqrt(sq[b]) + 1e-6));  norms[b] = scale*sqrt(sq[b])
+ * (norms may be NULL).  `scale` undoes the 1/B of a mean-reduced loss, so coef multiplies
+ * the raw backprops.  Opacus DPOptimizer.clip_and_accumulate. */
+int vqaf_clip_coef(const float* sq, int B, float max_norm, float scale, float* coef,
+                   float* norms, vqaf_stream_t stream);
+
+/* Clipped gradient sum of a Linear:  SW (Out,In) f32 = sum_b coef[b] g_b a_b^T,
+ * Sb (Out) f32 = sum_b coef[b] g_b (Sb may be NULL).  bf16 inputs use bf16 MFMA, f32
+ * inputs the exact f32 MFMA.  accumulate != 0 adds into SW / Sb (micro-batching). */
+int vqaf_clipped_sum_linear(const void* a, const void* g, const float* coef, int B, int In,
+                            int Out, int dtype, int accumulate, float* SW, float* Sb,
+                            vqaf_stream_t stream);
+
+/* Clipped gradient sums of an affine normalisation layer:
+ * Sgamma[c] = sum_b coef[b] xhat[b,c] g[b,c];  Sbeta[c] = sum_b coef[b] g[b,c]. */
+int vqaf_clipped_sum_affine(const void* xhat, const void* g, const float* coef, int B, int C,
+                            int dtype, int accumulate, float* Sgamma, float* Sbeta,
+                            vqaf_stream_t stream);
+
+/* grad[i] = (S[i] + noise_std * z_i) * scale  over n f32 elements
+ * (Opacus DPOptimizer.add_noise + scale_grad; noise_std = noise_multiplier * max_grad_norm,
+ * scale = 1/expected_batch_size).  z = noise[i] if `noise` is non-NULL, else N(0,1) drawn in
+ * the kernel from rng_state {seed, counter}; element i always uses draw (counter, i), so the
+ * result does not depend on the launch geometry.  grad may alias S. */
+int vqaf_noise_scale(const float* S, const float* noise, const uint64_t* rng_state,
+                     float noise_std, float scale, size_t n, float* grad, vqaf_stream_t stream);
+
+/* GroupNorm (+ optional ReLU) on (B,C) input, as the classifier holds after
+ * ModuleValidator.fix swaps BatchNorm1d for GroupNorm(min(32,C), C) (train.py:124;
+ * model/model.py:56-61).  Saves xhat (B,C) for the backward and the ghost norms. */
+int vqaf_groupnorm_fwd(const void* x, const void* gamma, const void* beta, int B, int C,
+                       int groups, float eps, int relu, int dtype, void* y, void* xhat,
+                       float* rstd, vqaf_stream_t stream);
+
+/* Backward of the above w.r.t. x only (parameter gradients come from the clipped sums).
+ * y is the forward output (for the ReLU mask); writes g_pre (B,C), the gradient at the
+ * GroupNorm output before the affine (what the ghost norms and clipped sums consume),
+ * and grad_x (B,C). */
+int vqaf_groupnorm_bwd(const void* grad_y, const void* y, const void* xhat, const float* rstd,
+                       const void* gamma, int B, int C, int groups, int relu, int dtype,
+                       void* g_pre, void* grad_x, vqaf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Membership-inference scoring: per-sample cross-entropy and max-softmax confidence.
+ * Replaces nn.CrossEntropyLoss(reduction='none') (attack/metric_src.py:313-314, 335, 354)
+ * and softmax -> max (attack/metric_src.py:376-377, 415).  logits (B,C) `dtype`,
+ * targets (B) int64; loss, conf (B) f32 and pred (B) int64 may each be NULL.
+ * grad_logits (B,C) f32, if non-NULL, receives grad_scale * (softmax - onehot): the
+ * backward of the mean-reduced training loss (utils/src.py:96,99) with grad_scale = 1/B.
+ * ------------------------------------------------------------------------------------ */
+int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, int C, int dtype,
+                 float* loss, float* conf, int64_t* pred, float* grad_logits, float grad_scale,
+                 vqaf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQAF_H_ */

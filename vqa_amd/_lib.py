@@ -1,0 +1,123 @@
+"""ctypes binding of libvqafuse.so (the C ABI declared in include/vqaf.h).
+
+The library is the product path: there is no CPU or PyTorch fallback.  Loading fails loudly
+if the shared object has not been built (``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C vqa_amd/csrc``), and every call checks the status code the C ABI returns.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqafuse.so")
+
+F32 = 0
+BF16 = 1
+NOISE_NONE, NOISE_GAUSSIAN, NOISE_UNIFORM = 0, 1, 2
+
+_P = c_void_p
+
+# name -> (restype, argtypes); mirrors include/vqaf.h one to one.
+SIGNATURES = {
+    "vqaf_version": (c_int, []),
+    "vqaf_status_string": (c_char_p, [c_int]),
+    "vqaf_fold_query": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "vqaf_head_scores": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vqaf_attn_weights": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "vqaf_score_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "vqaf_score": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t,
+                           _P, _P]),
+    "vqaf_topk": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "vqaf_adv_swap": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "vqaf_adv_swap_random": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "vqaf_rng_advance": (c_int, [_P, c_uint64, _P]),
+    "vqaf_gather_mix": (c_int, [_P, _P, _P, c_int, c_float, _P, c_float, c_int, c_int, c_int,
+                                c_int, c_int, c_int, _P, _P]),
+    "vqaf_gather_mix_bwd": (c_int, [_P, _P, c_float, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                    _P]),
+    "vqaf_mean_pool": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
+    "vqaf_mean_pool_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vqaf_gather_mix_pool": (c_int, [_P, _P, _P, c_int, c_float, _P, c_float, c_int, c_int, c_int,
+                                     c_int, c_int, _P, c_int, c_int, c_int, _P]),
+    "vqaf_gather_mix_pool_bwd": (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_int, c_int, c_int,
+                                         c_int, c_int, _P, _P]),
+    "vqaf_gemm_f32": (c_int, [_P, c_int, c_long, c_long, c_long, _P, c_int, c_long, c_long, c_long,
+                              _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
+                              c_float, c_int, _P]),
+    "vqaf_ghost_sqnorm_linear": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vqaf_ghost_sqnorm_affine": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "vqaf_clip_coef": (c_int, [_P, c_int, c_float, c_float, _P, _P, _P]),
+    "vqaf_clipped_sum_linear": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "vqaf_clipped_sum_affine": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "vqaf_noise_scale": (c_int, [_P, _P, _P, c_float, c_float, c_size_t, _P, _P]),
+    "vqaf_groupnorm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int, _P, _P,
+                                   _P, _P]),
+    "vqaf_groupnorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P,
+                                   _P]),
+    "vqaf_ce_conf": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P]),
+}
+
+_lib = None
+
+
+class VqafError(RuntimeError):
+    """A libvqafuse entry point returned a negative status."""
+
+
+def load(path: str | None = None) -> ctypes.CDLL:
+    """Loads the shared library once and types every symbol of SIGNATURES."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} is missing: build the HIP extension first (make -C vqa_amd/csrc, or "
+            "__graft_entry__.build()). There is no CPU fallback for the fusion kernels.")
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().vqaf_status_string(status).decode()
+        raise VqafError(f"{what} failed with status {status}: {msg}")
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"libvqafuse supports float32 and bfloat16 tensors, got {t.dtype}")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    """Device address of a contiguous CUDA/HIP tensor (None passes NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(
+            "libvqafuse kernels run on the GPU only; got a tensor on "
+            f"{t.device}. Move the module and its inputs to a HIP device.")
+    if not t.is_contiguous():
+        raise RuntimeError("libvqafuse needs contiguous tensors")
+    return t.data_ptr()
+
+
+def stream_ptr(device: torch.device | None = None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

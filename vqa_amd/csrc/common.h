@@ -1,0 +1,149 @@
+// Shared device/host helpers for the libvqafuse kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vqaf.h"
+
+#define VQAF_WAVE 64
+
+#define VQAF_REQUIRE(cond, code) \
+  do {                           \
+    if (!(cond)) return (code);  \
+  } while (0)
+
+#define VQAF_LAUNCH_CHECK() \
+  do { return hipGetLastError() == hipSuccess ? VQAF_OK : VQAF_E_LAUNCH; } while (0)
+
+static inline bool vqaf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool vqaf_dtype_ok(int d) { return d == VQAF_F32 || d == VQAF_BF16; }
+static inline size_t vqaf_esize(int d) { return d == VQAF_BF16 ? 2 : 4; }
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned int)h) << 16); }
+
+// Round-to-nearest-even f32 -> bf16; NaN stays NaN (quiet).
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+
+// Loads 8 consecutive elements starting at element offset `e` (multiple of 8) as f32.
+template <bool BF16>
+__device__ __forceinline__ void load8(const void* base, size_t e, float (&v)[8]) {
+  if constexpr (BF16) {
+    const u32x4 r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(base) + e);
+    v[0] = bf16_lo(r.x); v[1] = bf16_hi(r.x); v[2] = bf16_lo(r.y); v[3] = bf16_hi(r.y);
+    v[4] = bf16_lo(r.z); v[5] = bf16_hi(r.z); v[6] = bf16_lo(r.w); v[7] = bf16_hi(r.w);
+  } else {
+    const f32x4* p = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + e);
+    const f32x4 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+template <bool BF16>
+__device__ __forceinline__ void store8(void* base, size_t e, const float (&v)[8]) {
+  if constexpr (BF16) {
+    u32x4 r;
+    r.x = pack_bf16x2(v[0], v[1]); r.y = pack_bf16x2(v[2], v[3]);
+    r.z = pack_bf16x2(v[4], v[5]); r.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(base) + e) = r;
+  } else {
+    f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + e);
+    f32x4 a, b;
+    a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3]; b.x = v[4]; b.y = v[5]; b.z = v[6]; b.w = v[7];
+    p[0] = a; p[1] = b;
+  }
+}
+template <bool BF16>
+__device__ __forceinline__ float load1(const void* base, size_t e) {
+  if constexpr (BF16) return bf16_to_f32(reinterpret_cast<const bf16_t*>(base)[e]);
+  else return reinterpret_cast<const float*>(base)[e];
+}
+template <bool BF16>
+__device__ __forceinline__ void store1(void* base, size_t e, float v) {
+  if constexpr (BF16) reinterpret_cast<bf16_t*>(base)[e] = f32_to_bf16(v);
+  else reinterpret_cast<float*>(base)[e] = v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Counter-based RNG: Philox4x32-10 (Salmon et al., SC'11).  A draw is addressed by
+// (seed, counter, subsequence, index): results depend on those four numbers only, never on
+// the launch geometry, so every kernel that consumes randomness is reproducible and can be
+// re-checked on the host.
+// ---------------------------------------------------------------------------------------
+struct Philox4 {
+  unsigned int x, y, z, w;
+};
+__host__ __device__ __forceinline__ unsigned int vqaf_mulhi32(unsigned int a, unsigned int b) {
+  return (unsigned int)(((unsigned long long)a * (unsigned long long)b) >> 32);
+}
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(unsigned long long seed,
+                                                          unsigned long long ctr_lo,
+                                                          unsigned long long ctr_hi) {
+  unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+  Philox4 c = {(unsigned int)ctr_lo, (unsigned int)(ctr_lo >> 32), (unsigned int)ctr_hi,
+               (unsigned int)(ctr_hi >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned int hi0 = vqaf_mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const unsigned int hi1 = vqaf_mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    Philox4 n = {hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+// (0,1] uniform from 32 random bits (never 0, so log() is finite): (r + 0.5) * 2^-32.
+__host__ __device__ __forceinline__ float vqaf_u01(unsigned int r) {
+  return ((float)r + 0.5f) * 2.3283064365386963e-10f;
+}
+// Two independent N(0,1) from two 32-bit words (Box-Muller).
+__device__ __forceinline__ void vqaf_box_muller(unsigned int a, unsigned int b, float& n0, float& n1) {
+  const float u = vqaf_u01(a), v = vqaf_u01(b);
+  const float r = sqrtf(-2.0f * logf(u));
+  float s, c;
+  sincospif(2.0f * v, &s, &c);
+  n0 = r * c;
+  n1 = r * s;
+}
+// Draw `call` of stream (seed, counter) -> four N(0,1) values z[0..3].
+__device__ __forceinline__ void vqaf_normal4(unsigned long long seed, unsigned long long counter,
+                                             unsigned long long call, float (&z)[4]) {
+  const Philox4 r = philox4x32_10(seed, call, counter);
+  vqaf_box_muller(r.x, r.y, z[0], z[1]);
+  vqaf_box_muller(r.z, r.w, z[2], z[3]);
+}
+// Same draw as four U(-1,1) values.
+__device__ __forceinline__ void vqaf_uniform4(unsigned long long seed, unsigned long long counter,
+                                              unsigned long long call, float (&z)[4]) {
+  const Philox4 r = philox4x32_10(seed, call, counter);
+  z[0] = 2.0f * vqaf_u01(r.x) - 1.0f; z[1] = 2.0f * vqaf_u01(r.y) - 1.0f;
+  z[2] = 2.0f * vqaf_u01(r.z) - 1.0f; z[3] = 2.0f * vqaf_u01(r.w) - 1.0f;
+}

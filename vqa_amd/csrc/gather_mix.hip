@@ -1,0 +1,623 @@
+// Gather / noise / remaining-mean mix token, its pooled variant, and their backward passes.
+//
+// Data layout: seq (B,N,D) row-major, one token row = D*s contiguous bytes.  A workgroup owns
+// one (sample, column slice) pair: a slice is 8*LPR consecutive columns, handled by LPR lanes
+// that each move 8 elements (16 B of bf16, 32 B of f32) per row, so a 256-thread workgroup has
+// 256/LPR rows in flight per step and every row is read from HBM exactly once by exactly one
+// workgroup.  Because a workgroup sees every token of its sample, the mix token (a sum over
+// the dropped rows) needs no cross-workgroup reduction and no atomics: the sum order is fixed.
+#include "common.h"
+
+namespace {
+
+constexpr int GM_THREADS = 256;
+constexpr int GM_UNROLL = 4;
+
+__device__ __forceinline__ void zero8(float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+}
+
+// Adds the 8 noise values of elements [e, e+8) (e multiple of 8) to v.
+__device__ __forceinline__ void add_noise8(float (&v)[8], const float* noise, int noise_kind,
+                                           float noise_scale, unsigned long long seed,
+                                           unsigned long long counter, size_t e) {
+  if (noise != nullptr) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(noise + e);
+    const f32x4 a = p[0], b = p[1];
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+    v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  } else if (noise_kind != VQAF_NOISE_NONE) {
+    float z0[4], z1[4];
+    if (noise_kind == VQAF_NOISE_GAUSSIAN) {
+      vqaf_normal4(seed, counter, e >> 2, z0);
+      vqaf_normal4(seed, counter, (e >> 2) + 1, z1);
+    } else {
+      vqaf_uniform4(seed, counter, e >> 2, z0);
+      vqaf_uniform4(seed, counter, (e >> 2) + 1, z1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] += noise_scale * z0[i];
+      v[4 + i] += noise_scale * z1[i];
+    }
+  }
+}
+
+// Shared-memory carve for the forward kernels.
+struct FwdSmem {
+  int* sidx;             // [K]  clamped index or -1
+  unsigned char* kept;   // [N]
+  unsigned short* drop;  // [N]  compacted list of dropped rows
+  float* red;            // [GM_THREADS * 8]
+  int* misc;             // [4]
+};
+__host__ __device__ inline size_t fwd_smem_bytes(int N, int K) {
+  size_t b = 0;
+  b += ((size_t)K * 4 + 15) & ~(size_t)15;
+  b += ((size_t)N + 15) & ~(size_t)15;
+  b += ((size_t)N * 2 + 15) & ~(size_t)15;
+  b += (size_t)GM_THREADS * 8 * 4;
+  b += 16;
+  return b;
+}
+__device__ inline FwdSmem fwd_carve(unsigned char* base, int N, int K) {
+  FwdSmem s;
+  s.sidx = reinterpret_cast<int*>(base);
+  base += ((size_t)K * 4 + 15) & ~(size_t)15;
+  s.kept = base;
+  base += ((size_t)N + 15) & ~(size_t)15;
+  s.drop = reinterpret_cast<unsigned short*>(base);
+  base += ((size_t)N * 2 + 15) & ~(size_t)15;
+  s.red = reinterpret_cast<float*>(base);
+  base += (size_t)GM_THREADS * 8 * 4;
+  s.misc = reinterpret_cast<int*>(base);
+  return s;
+}
+
+// POOL == false: out is (B, Kout, D) with Kout = K + (alpha > 0).
+// POOL == true : out is (B, ld_out); writes columns [col0, col0 + D) with the token mean.
+template <bool BF16, bool BF16_OUT, int LPR, bool POOL>
+__global__ void __launch_bounds__(GM_THREADS)
+gather_mix_kernel(const void* __restrict__ seq, const int64_t* __restrict__ idx,
+                  const float* __restrict__ noise, int noise_kind, float noise_scale,
+                  const uint64_t* __restrict__ rng_state, float alpha, int N, int K, int D,
+                  void* __restrict__ out, int ld_out, int col0) {
+  constexpr int ROWS = GM_THREADS / LPR;
+  constexpr int SLW = 8 * LPR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const FwdSmem sm = fwd_carve(smem_raw, N, K);
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int g = tid / LPR;
+  const int li = tid % LPR;
+  const int d0 = blockIdx.x * SLW + li * 8;
+  const bool active = d0 < D;
+  const bool with_mix = alpha > 0.f;
+  const int Kout = K + (with_mix ? 1 : 0);
+  const bool has_noise = (noise != nullptr) || (noise_kind != VQAF_NOISE_NONE);
+
+  unsigned long long seed = 0, counter = 0;
+  if (noise == nullptr && noise_kind != VQAF_NOISE_NONE) {
+    seed = rng_state[0];
+    counter = rng_state[1];
+  }
+
+  // ---- index staging: sidx[j], kept[n] ----
+  for (int n = tid; n < N; n += GM_THREADS) sm.kept[n] = 0;
+  __syncthreads();
+  const int64_t* idx_b = idx + (size_t)b * K;
+  for (int j = tid; j < K; j += GM_THREADS) {
+    const int64_t n = idx_b[j];
+    const bool ok = n >= 0 && n < (int64_t)N;
+    sm.sidx[j] = ok ? (int)n : -1;
+    if (ok) sm.kept[n] = 1;
+  }
+  __syncthreads();
+
+  // ---- wave 0: compact the dropped rows, ascending ----
+  if (with_mix && tid < VQAF_WAVE) {
+    int cnt = 0;
+    for (int base = 0; base < N; base += VQAF_WAVE) {
+      const int n = base + tid;
+      const bool dr = (n < N) && (sm.kept[n] == 0);
+      const unsigned long long m = __ballot(dr);
+      if (dr) sm.drop[cnt + __popcll(m & ((1ull << tid) - 1ull))] = (unsigned short)n;
+      cnt += __popcll(m);
+    }
+    if (tid == 0) sm.misc[0] = cnt;
+  }
+
+  const size_t seq_b = (size_t)b * N * D;
+  float acc[8];
+  zero8(acc);
+
+  // ---- gather phase ----
+  if (active) {
+    for (int j0 = g; j0 < K; j0 += GM_UNROLL * ROWS) {
+      if (!POOL && BF16 == BF16_OUT && !has_noise) {
+        // raw copy: bit-exact for every payload, NaNs included
+        constexpr int W = BF16 ? 1 : 2;  // 16-byte pieces per lane
+        u32x4 raw[GM_UNROLL][W];
+#pragma unroll
+        for (int u = 0; u < GM_UNROLL; ++u) {
+          const int j = j0 + u * ROWS;
+          const int n = (j < K) ? sm.sidx[j] : -1;
+#pragma unroll
+          for (int w = 0; w < W; ++w) raw[u][w] = u32x4{0u, 0u, 0u, 0u};
+          if (n >= 0) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(
+                reinterpret_cast<const unsigned char*>(seq) +
+                (seq_b + (size_t)n * D + d0) * (BF16 ? 2 : 4));
+#pragma unroll
+            for (int w = 0; w < W; ++w) raw[u][w] = src[w];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GM_UNROLL; ++u) {
+          const int j = j0 + u * ROWS;
+          if (j < K) {
+            u32x4* dst = reinterpret_cast<u32x4*>(
+                reinterpret_cast<unsigned char*>(out) +
+                (((size_t)b * Kout + j) * D + d0) * (BF16 ? 2 : 4));
+#pragma unroll
+            for (int w = 0; w < W; ++w) dst[w] = raw[u][w];
+          }
+        }
+      } else {
+        float v[GM_UNROLL][8];
+#pragma unroll
+        for (int u = 0; u < GM_UNROLL; ++u) {
+          const int j = j0 + u * ROWS;
+          const int n = (j < K) ? sm.sidx[j] : -1;
+          zero8(v[u]);
+          if (n >= 0) load8<BF16>(seq, seq_b + (size_t)n * D + d0, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < GM_UNROLL; ++u) {
+          const int j = j0 + u * ROWS;
+          if (j < K) {
+            if (has_noise)
+              add_noise8(v[u], noise, noise_kind, noise_scale, seed, counter,
+                         ((size_t)b * K + j) * D + d0);
+            if constexpr (POOL) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) acc[i] += v[u][i];
+            } else {
+              store8<BF16_OUT>(out, ((size_t)b * Kout + j) * D + d0, v[u]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!with_mix && !POOL) return;
+  __syncthreads();  // drop list + count visible
+
+  // ---- mix phase: fixed-order f32 sum over the dropped rows ----
+  float accd[8];
+  zero8(accd);
+  const int R = with_mix ? sm.misc[0] : 0;
+  if (active && with_mix) {
+    for (int r0 = g; r0 < R; r0 += GM_UNROLL * ROWS) {
+      float v[GM_UNROLL][8];
+#pragma unroll
+      for (int u = 0; u < GM_UNROLL; ++u) {
+        const int r = r0 + u * ROWS;
+        zero8(v[u]);
+        if (r < R) load8<BF16>(seq, seq_b + (size_t)sm.drop[r] * D + d0, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < GM_UNROLL; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) accd[i] += v[u][i];
+    }
+  }
+  // remaining_sum / (count + 1e-10), then * alpha  (same op order as the reference)
+  const float cnt = (float)R + 1e-10f;
+  if constexpr (POOL) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm.red[tid * 8 + i] = acc[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm.red[tid * 8 + i] = accd[i];
+  }
+  __syncthreads();
+  if constexpr (POOL) {
+    // two reductions share the buffer: selected rows first, then dropped rows
+    float sel = 0.f;
+    const int c = tid;  // column within the slice
+    if (c < SLW) {
+      for (int gg = 0; gg < ROWS; ++gg) sel += sm.red[(gg * LPR + c / 8) * 8 + (c & 7)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm.red[tid * 8 + i] = accd[i];
+    __syncthreads();
+    if (c < SLW) {
+      float dr = 0.f;
+      for (int gg = 0; gg < ROWS; ++gg) dr += sm.red[(gg * LPR + c / 8) * 8 + (c & 7)];
+      const int d = blockIdx.x * SLW + c;
+      if (d < D) {
+        float tot = sel;
+        if (with_mix) tot += alpha * (dr / cnt);
+        tot /= (float)Kout;
+        store1<BF16_OUT>(out, (size_t)b * ld_out + col0 + d, tot);
+      }
+    }
+  } else {
+    const int c = tid;
+    if (c < SLW) {
+      float dr = 0.f;
+      for (int gg = 0; gg < ROWS; ++gg) dr += sm.red[(gg * LPR + c / 8) * 8 + (c & 7)];
+      const int d = blockIdx.x * SLW + c;
+      if (d < D) store1<BF16_OUT>(out, ((size_t)b * Kout + K) * D + d, alpha * (dr / cnt));
+    }
+  }
+}
+
+// ------------------------------- backward -------------------------------------------------
+__host__ __device__ inline size_t bwd_smem_bytes(int N, int K) {
+  return (((size_t)K * 4 + 15) & ~(size_t)15) + (((size_t)N * 4 + 15) & ~(size_t)15) + 16;
+}
+
+// POOL == false: grad_out is (B, Kout, D).  POOL == true: grad_out is (B, ld_out), columns
+// [col0, col0+D).  pos[n] = smallest j with idx[j] == n (INT_MAX if dropped); for POOL it
+// holds the multiplicity of n in idx instead.
+template <bool BF16_G, bool BF16, int LPR, bool POOL>
+__global__ void __launch_bounds__(GM_THREADS)
+gather_mix_bwd_kernel(const void* __restrict__ grad_out, int ld_out, int col0,
+                      const int64_t* __restrict__ idx, float alpha, int N, int K, int D,
+                      void* __restrict__ grad_seq) {
+  constexpr int ROWS = GM_THREADS / LPR;
+  constexpr int SLW = 8 * LPR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int* sidx = reinterpret_cast<int*>(smem_raw);
+  int* pos = reinterpret_cast<int*>(smem_raw + (((size_t)K * 4 + 15) & ~(size_t)15));
+  int* misc = reinterpret_cast<int*>(smem_raw + (((size_t)K * 4 + 15) & ~(size_t)15) +
+                                     (((size_t)N * 4 + 15) & ~(size_t)15));
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int g = tid / LPR;
+  const int li = tid % LPR;
+  const int d0 = blockIdx.x * SLW + li * 8;
+  const bool active = d0 < D;
+  const bool with_mix = alpha > 0.f;
+  const int Kout = K + (with_mix ? 1 : 0);
+  constexpr int NONE = POOL ? 0 : 0x7fffffff;
+
+  for (int n = tid; n < N; n += GM_THREADS) pos[n] = NONE;
+  if (tid < 2) misc[tid] = 0;
+  __syncthreads();
+  const int64_t* idx_b = idx + (size_t)b * K;
+  for (int j = tid; j < K; j += GM_THREADS) {
+    const int64_t n = idx_b[j];
+    const bool ok = n >= 0 && n < (int64_t)N;
+    sidx[j] = ok ? (int)n : -1;
+    if (ok) {
+      if constexpr (POOL) atomicAdd(&pos[n], 1);
+      else atomicMin(&pos[n], j);
+    }
+  }
+  __syncthreads();
+  {  // count dropped rows; detect duplicate indices
+    int local = 0;
+    for (int n = tid; n < N; n += GM_THREADS) local += (pos[n] == NONE) ? 1 : 0;
+    if (local) atomicAdd(&misc[0], local);
+    if constexpr (!POOL) {
+      int dup = 0;
+      for (int j = tid; j < K; j += GM_THREADS) {
+        const int n = sidx[j];
+        if (n >= 0 && pos[n] != j) dup = 1;
+      }
+      if (dup) atomicOr(&misc[1], 1);
+    }
+  }
+  __syncthreads();
+  const int R = misc[0];
+  const float cnt = (float)R + 1e-10f;
+  const size_t seq_b = (size_t)b * N * D;
+
+  if (active) {
+    float gmix[8], gsel[8];
+    zero8(gmix);
+    zero8(gsel);
+    if constexpr (POOL) {
+      // pooled = (sum_sel + alpha * sum_drop / cnt) / Kout
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float go = load1<BF16_G>(grad_out, (size_t)b * ld_out + col0 + d0 + i) / (float)Kout;
+        gsel[i] = go;
+        gmix[i] = with_mix ? (alpha * go) / cnt : 0.f;
+      }
+    } else if (with_mix) {
+      float t[8];
+      load8<BF16_G>(grad_out, ((size_t)b * Kout + K) * D + d0, t);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gmix[i] = (alpha * t[i]) / cnt;
+    }
+    for (int n0 = g; n0 < N; n0 += GM_UNROLL * ROWS) {
+      float v[GM_UNROLL][8];
+#pragma unroll
+      for (int u = 0; u < GM_UNROLL; ++u) {
+        const int n = n0 + u * ROWS;
+        if (n < N) {
+          const int p = pos[n];
+          if constexpr (POOL) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[u][i] = (p == 0) ? gmix[i] : gsel[i] * (float)p;
+          } else {
+            if (p == NONE) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[u][i] = gmix[i];
+            } else {
+              load8<BF16_G>(grad_out, ((size_t)b * Kout + p) * D + d0, v[u]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GM_UNROLL; ++u) {
+        const int n = n0 + u * ROWS;
+        if (n < N) store8<BF16>(grad_seq, seq_b + (size_t)n * D + d0, v[u]);
+      }
+    }
+  }
+  if constexpr (!POOL) {
+    if (misc[1] != 0) {
+      // Duplicate indices (never produced by the pruning module itself): add the rows that
+      // lost the race, in j order, by the same lanes that wrote the row.
+      __syncthreads();
+      for (int j = 0; j < K; ++j) {
+        const int n = sidx[j];
+        if (n >= 0 && pos[n] != j && g == 0 && active) {
+          float a[8], c[8];
+          load8<BF16>(grad_seq, seq_b + (size_t)n * D + d0, a);
+          load8<BF16_G>(grad_out, ((size_t)b * Kout + j) * D + d0, c);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) a[i] += c[i];
+          store8<BF16>(grad_seq, seq_b + (size_t)n * D + d0, a);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------- plain mean pool ------------------------------------------
+template <bool BF16, bool BF16_OUT, int LPR>
+__global__ void __launch_bounds__(GM_THREADS)
+mean_pool_kernel(const void* __restrict__ x, int M, int D, void* __restrict__ out, int ld_out,
+                 int col0) {
+  constexpr int ROWS = GM_THREADS / LPR;
+  constexpr int SLW = 8 * LPR;
+  __shared__ float red[GM_THREADS * 8];
+  const int tid = threadIdx.x, b = blockIdx.y, g = tid / LPR, li = tid % LPR;
+  const int d0 = blockIdx.x * SLW + li * 8;
+  float acc[8];
+  zero8(acc);
+  if (d0 < D) {
+    for (int j0 = g; j0 < M; j0 += GM_UNROLL * ROWS) {
+      float v[GM_UNROLL][8];
+#pragma unroll
+      for (int u = 0; u < GM_UNROLL; ++u) {
+        const int j = j0 + u * ROWS;
+        zero8(v[u]);
+        if (j < M) load8<BF16>(x, ((size_t)b * M + j) * D + d0, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < GM_UNROLL; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += v[u][i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[tid * 8 + i] = acc[i];
+  __syncthreads();
+  const int c = tid;
+  if (c < SLW) {
+    float s = 0.f;
+    for (int gg = 0; gg < ROWS; ++gg) s += red[(gg * LPR + c / 8) * 8 + (c & 7)];
+    const int d = blockIdx.x * SLW + c;
+    if (d < D) store1<BF16_OUT>(out, (size_t)b * ld_out + col0 + d, s / (float)M);
+  }
+}
+
+template <bool BF16_G, bool BF16, int LPR>
+__global__ void __launch_bounds__(GM_THREADS)
+mean_pool_bwd_kernel(const void* __restrict__ grad_out, int ld_out, int col0, int M, int D,
+                     void* __restrict__ grad_x) {
+  constexpr int ROWS = GM_THREADS / LPR;
+  constexpr int SLW = 8 * LPR;
+  const int tid = threadIdx.x, b = blockIdx.y, g = tid / LPR, li = tid % LPR;
+  const int d0 = blockIdx.x * SLW + li * 8;
+  if (d0 >= D) return;
+  float gv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    gv[i] = load1<BF16_G>(grad_out, (size_t)b * ld_out + col0 + d0 + i) / (float)M;
+  for (int j = g; j < M; j += ROWS) store8<BF16>(grad_x, ((size_t)b * M + j) * D + d0, gv);
+}
+
+// Picks the slice width so that small batches still launch >= ~1024 workgroups.
+inline int pick_lpr(int B, int D) {
+  const int slices16 = (D + 127) / 128;
+  return ((long)B * slices16 >= 1024) ? 16 : 8;
+}
+
+template <bool POOL>
+int launch_fwd(const void* seq, const int64_t* idx, const float* noise, int noise_kind,
+               float noise_scale, const uint64_t* rng_state, float alpha, int B, int N, int K,
+               int D, int dtype, int out_dtype, void* out, int ld_out, int col0,
+               hipStream_t st) {
+  const int lpr = pick_lpr(B, D);
+  const dim3 grid((D + 8 * lpr - 1) / (8 * lpr), B), block(GM_THREADS);
+  const size_t smem = fwd_smem_bytes(N, K);
+#define VQAF_GM_LAUNCH(BF, BFO, L)                                                              \
+  hipLaunchKernelGGL((gather_mix_kernel<BF, BFO, L, POOL>), grid, block, smem, st, seq, idx,     \
+                     noise, noise_kind, noise_scale, rng_state, alpha, N, K, D, out, ld_out, col0)
+  const bool bf = dtype == VQAF_BF16, bfo = out_dtype == VQAF_BF16;
+  if (lpr == 16) {
+    if (bf && bfo) VQAF_GM_LAUNCH(true, true, 16);
+    else if (bf) VQAF_GM_LAUNCH(true, false, 16);
+    else if (!bfo) VQAF_GM_LAUNCH(false, false, 16);
+    else VQAF_GM_LAUNCH(false, true, 16);
+  } else {
+    if (bf && bfo) VQAF_GM_LAUNCH(true, true, 8);
+    else if (bf) VQAF_GM_LAUNCH(true, false, 8);
+    else if (!bfo) VQAF_GM_LAUNCH(false, false, 8);
+    else VQAF_GM_LAUNCH(false, true, 8);
+  }
+#undef VQAF_GM_LAUNCH
+  VQAF_LAUNCH_CHECK();
+}
+
+template <bool POOL>
+int launch_bwd(const void* grad_out, int ld_out, int col0, int g_dtype, const int64_t* idx,
+               float alpha, int B, int N, int K, int D, int dtype, void* grad_seq,
+               hipStream_t st) {
+  const int lpr = pick_lpr(B, D);
+  const dim3 grid((D + 8 * lpr - 1) / (8 * lpr), B), block(GM_THREADS);
+  const size_t smem = bwd_smem_bytes(N, K);
+#define VQAF_GMB_LAUNCH(BFG, BF, L)                                                         \
+  hipLaunchKernelGGL((gather_mix_bwd_kernel<BFG, BF, L, POOL>), grid, block, smem, st,       \
+                     grad_out, ld_out, col0, idx, alpha, N, K, D, grad_seq)
+  const bool bfg = g_dtype == VQAF_BF16, bf = dtype == VQAF_BF16;
+  if (lpr == 16) {
+    if (bfg && bf) VQAF_GMB_LAUNCH(true, true, 16);
+    else if (bfg) VQAF_GMB_LAUNCH(true, false, 16);
+    else if (bf) VQAF_GMB_LAUNCH(false, true, 16);
+    else VQAF_GMB_LAUNCH(false, false, 16);
+  } else {
+    if (bfg && bf) VQAF_GMB_LAUNCH(true, true, 8);
+    else if (bfg) VQAF_GMB_LAUNCH(true, false, 8);
+    else if (bf) VQAF_GMB_LAUNCH(false, true, 8);
+    else VQAF_GMB_LAUNCH(false, false, 8);
+  }
+#undef VQAF_GMB_LAUNCH
+  VQAF_LAUNCH_CHECK();
+}
+
+int check_common(const void* seq, const int64_t* idx, int B, int N, int K, int D, int dtype,
+                 int out_dtype) {
+  VQAF_REQUIRE(seq != nullptr && idx != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(out_dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(B > 0 && N > 0 && K > 0 && K <= N && D > 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(N <= 16384 && B <= 65535, VQAF_E_SHAPE);
+  VQAF_REQUIRE(D % 8 == 0, VQAF_E_ALIGN);
+  VQAF_REQUIRE(vqaf_aligned16(seq), VQAF_E_ALIGN);
+  return VQAF_OK;
+}
+
+}  // namespace
+
+extern "C" int vqaf_gather_mix(const void* seq, const int64_t* idx, const float* noise,
+                               int noise_kind, float noise_scale, const uint64_t* rng_state,
+                               float alpha, int B, int N, int K, int D, int dtype, int out_dtype,
+                               void* out, vqaf_stream_t stream) {
+  const int rc = check_common(seq, idx, B, N, K, D, dtype, out_dtype);
+  if (rc != VQAF_OK) return rc;
+  VQAF_REQUIRE(out != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_aligned16(out) && (noise == nullptr || vqaf_aligned16(noise)), VQAF_E_ALIGN);
+  VQAF_REQUIRE(noise_kind >= VQAF_NOISE_NONE && noise_kind <= VQAF_NOISE_UNIFORM, VQAF_E_SHAPE);
+  VQAF_REQUIRE(noise != nullptr || noise_kind == VQAF_NOISE_NONE || rng_state != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(!(out_dtype == VQAF_BF16 && dtype == VQAF_F32), VQAF_E_DTYPE);
+  return launch_fwd<false>(seq, idx, noise, noise_kind, noise_scale, rng_state, alpha, B, N, K, D,
+                           dtype, out_dtype, out, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int vqaf_gather_mix_pool(const void* seq, const int64_t* idx, const float* noise,
+                                    int noise_kind, float noise_scale, const uint64_t* rng_state,
+                                    float alpha, int B, int N, int K, int D, int dtype, void* out,
+                                    int ld_out, int col0, int out_dtype, vqaf_stream_t stream) {
+  const int rc = check_common(seq, idx, B, N, K, D, dtype, out_dtype);
+  if (rc != VQAF_OK) return rc;
+  VQAF_REQUIRE(out != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(noise == nullptr || vqaf_aligned16(noise), VQAF_E_ALIGN);
+  VQAF_REQUIRE(noise_kind >= VQAF_NOISE_NONE && noise_kind <= VQAF_NOISE_UNIFORM, VQAF_E_SHAPE);
+  VQAF_REQUIRE(noise != nullptr || noise_kind == VQAF_NOISE_NONE || rng_state != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(col0 >= 0 && ld_out >= col0 + D, VQAF_E_SHAPE);
+  return launch_fwd<true>(seq, idx, noise, noise_kind, noise_scale, rng_state, alpha, B, N, K, D,
+                          dtype, out_dtype, out, ld_out, col0, (hipStream_t)stream);
+}
+
+extern "C" int vqaf_gather_mix_bwd(const void* grad_out, const int64_t* idx, float alpha, int B,
+                                   int N, int K, int D, int g_dtype, int dtype, void* grad_seq,
+                                   vqaf_stream_t stream) {
+  const int rc = check_common(grad_out, idx, B, N, K, D, g_dtype, dtype);
+  if (rc != VQAF_OK) return rc;
+  VQAF_REQUIRE(grad_seq != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_aligned16(grad_seq), VQAF_E_ALIGN);
+  return launch_bwd<false>(grad_out, 0, 0, g_dtype, idx, alpha, B, N, K, D, dtype, grad_seq,
+                           (hipStream_t)stream);
+}
+
+extern "C" int vqaf_gather_mix_pool_bwd(const void* grad_out, int ld_out, int col0, int g_dtype,
+                                        const int64_t* idx, float alpha, int B, int N, int K,
+                                        int D, int dtype, void* grad_seq, vqaf_stream_t stream) {
+  VQAF_REQUIRE(grad_out != nullptr && idx != nullptr && grad_seq != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(g_dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(B > 0 && N > 0 && K > 0 && K <= N && D > 0 && N <= 16384 && B <= 65535, VQAF_E_SHAPE);
+  VQAF_REQUIRE(col0 >= 0 && ld_out >= col0 + D, VQAF_E_SHAPE);
+  VQAF_REQUIRE(D % 8 == 0 && vqaf_aligned16(grad_seq), VQAF_E_ALIGN);
+  return launch_bwd<true>(grad_out, ld_out, col0, g_dtype, idx, alpha, B, N, K, D, dtype, grad_seq,
+                          (hipStream_t)stream);
+}
+
+extern "C" int vqaf_mean_pool(const void* x, int B, int M, int D, int dtype, void* out, int ld_out,
+                              int col0, int out_dtype, vqaf_stream_t stream) {
+  VQAF_REQUIRE(x != nullptr && out != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(out_dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(B > 0 && M > 0 && D > 0 && B <= 65535, VQAF_E_SHAPE);
+  VQAF_REQUIRE(col0 >= 0 && ld_out >= col0 + D, VQAF_E_SHAPE);
+  VQAF_REQUIRE(D % 8 == 0 && vqaf_aligned16(x), VQAF_E_ALIGN);
+  const int lpr = pick_lpr(B, D);
+  const dim3 grid((D + 8 * lpr - 1) / (8 * lpr), B), block(GM_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+#define VQAF_MP_LAUNCH(BF, BFO, L) \
+  hipLaunchKernelGGL((mean_pool_kernel<BF, BFO, L>), grid, block, 0, st, x, M, D, out, ld_out, col0)
+  const bool bf = dtype == VQAF_BF16, bfo = out_dtype == VQAF_BF16;
+  if (lpr == 16) {
+    if (bf && bfo) VQAF_MP_LAUNCH(true, true, 16);
+    else if (bf) VQAF_MP_LAUNCH(true, false, 16);
+    else if (bfo) VQAF_MP_LAUNCH(false, true, 16);
+    else VQAF_MP_LAUNCH(false, false, 16);
+  } else {
+    if (bf && bfo) VQAF_MP_LAUNCH(true, true, 8);
+    else if (bf) VQAF_MP_LAUNCH(true, false, 8);
+    else if (bfo) VQAF_MP_LAUNCH(false, true, 8);
+    else VQAF_MP_LAUNCH(false, false, 8);
+  }
+#undef VQAF_MP_LAUNCH
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_mean_pool_bwd(const void* grad_out, int ld_out, int col0, int g_dtype, int B,
+                                  int M, int D, int dtype, void* grad_x, vqaf_stream_t stream) {
+  VQAF_REQUIRE(grad_out != nullptr && grad_x != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(g_dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(B > 0 && M > 0 && D > 0 && B <= 65535, VQAF_E_SHAPE);
+  VQAF_REQUIRE(col0 >= 0 && ld_out >= col0 + D, VQAF_E_SHAPE);
+  VQAF_REQUIRE(D % 8 == 0 && vqaf_aligned16(grad_x), VQAF_E_ALIGN);
+  const int lpr = pick_lpr(B, D);
+  const dim3 grid((D + 8 * lpr - 1) / (8 * lpr), B), block(GM_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+#define VQAF_MPB_LAUNCH(BFG, BF, L)                                                            \
+  hipLaunchKernelGGL((mean_pool_bwd_kernel<BFG, BF, L>), grid, block, 0, st, grad_out, ld_out, \
+                     col0, M, D, grad_x)
+  const bool bfg = g_dtype == VQAF_BF16, bf = dtype == VQAF_BF16;
+  if (lpr == 16) {
+    if (bfg && bf) VQAF_MPB_LAUNCH(true, true, 16);
+    else if (bfg) VQAF_MPB_LAUNCH(true, false, 16);
+    else if (bf) VQAF_MPB_LAUNCH(false, true, 16);
+    else VQAF_MPB_LAUNCH(false, false, 16);
+  } else {
+    if (bfg && bf) VQAF_MPB_LAUNCH(true, true, 8);
+    else if (bfg) VQAF_MPB_LAUNCH(true, false, 8);
+    else if (bf) VQAF_MPB_LAUNCH(false, true, 8);
+    else VQAF_MPB_LAUNCH(false, false, 8);
+  }
+#undef VQAF_MPB_LAUNCH
+  VQAF_LAUNCH_CHECK();
+}

@@ -1,0 +1,285 @@
+// Token scoring: head-averaged single-query attention weights without projecting the keys.
+//
+// For one query per sample the key projection folds into the query:
+//   (Wq_h q + bq_h) . (Wk_h x_n + bk_h) / sqrt(dh) = x_n . u_h + const_h,
+//   u_h = Wk_h^T (Wq_h q + bq_h) / sqrt(dh),
+// and const_h cancels in the softmax over n.  So scoring is one streaming pass over the tokens
+// with H dot products of length D per token: bandwidth-bound (16 flop per bf16 element).
+//
+// head_scores_kernel: a wave owns a token at a time.  The 64 lanes each hold 8 consecutive
+// columns of the row (one 16-byte load for bf16, two for f32: fully coalesced 1-2 KiB per
+// wave-instruction) and the matching 8 x H slice of u in registers.  The H partial sums per
+// lane are combined with a halving exchange (4+2+1 shuffles for H = 8) followed by a 3-step
+// butterfly, instead of H full 6-step reductions.
+#include "common.h"
+
+namespace {
+
+constexpr int SC_THREADS = 256;
+constexpr int SC_WAVES = SC_THREADS / VQAF_WAVE;
+constexpr int SC_UNROLL = 4;
+
+template <int HP>
+struct Log2 { static constexpr int v = 1 + Log2<HP / 2>::v; };
+template <>
+struct Log2<1> { static constexpr int v = 0; };
+
+// Reduces part[0..HP) over the 64 lanes.  On return every lane holds in part[0] the total of
+// head (lane >> (6 - log2 HP)).
+template <int HP>
+__device__ __forceinline__ void heads_reduce(float (&part)[HP], int lane) {
+  constexpr int LG = Log2<HP>::v;
+  int cnt = HP;
+#pragma unroll
+  for (int s = 0; s < LG; ++s) {
+    const int off = 32 >> s;
+    const bool hi = (lane & off) != 0;
+    const int half = cnt >> 1;
+#pragma unroll
+    for (int i = 0; i < HP / 2; ++i) {
+      if (i < half) {
+        const float keep = hi ? part[i + half] : part[i];
+        const float send = hi ? part[i] : part[i + half];
+        part[i] = keep + __shfl_xor(send, off, 64);
+      }
+    }
+    cnt = half;
+  }
+#pragma unroll
+  for (int off = (32 >> LG); off > 0; off >>= 1) part[0] += __shfl_xor(part[0], off, 64);
+}
+
+// CH = number of 512-column chunks (D <= 512*CH).  Lane l covers columns [512c + 8l, +8).
+template <bool BF16, int HP, int CH>
+__global__ void __launch_bounds__(SC_THREADS)
+head_scores_kernel(const void* __restrict__ seq, const float* __restrict__ u, int N, int D, int H,
+                   int tokb, float* __restrict__ s) {
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * tokb;
+  const int t1 = min(N, t0 + tokb);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  float ur[CH][HP][8];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = 512 * c + 8 * lane;
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+      if (h < H && col < D) {
+        load8<false>(u, ((size_t)b * H + h) * D + col, ur[c][h]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ur[c][h][i] = 0.f;
+      }
+    }
+  }
+  const size_t seq_b = (size_t)b * N * D;
+  constexpr int LG = Log2<HP>::v;
+  for (int t = t0 + wave; t < t1; t += SC_WAVES * SC_UNROLL) {
+    float x[SC_UNROLL][CH][8];
+#pragma unroll
+    for (int uu = 0; uu < SC_UNROLL; ++uu) {
+      const int tt = t + uu * SC_WAVES;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int col = 512 * c + 8 * lane;
+        if (tt < t1 && col < D) {
+          load8<BF16>(seq, seq_b + (size_t)tt * D + col, x[uu][c]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[uu][c][i] = 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int uu = 0; uu < SC_UNROLL; ++uu) {
+      const int tt = t + uu * SC_WAVES;
+      float part[HP];
+#pragma unroll
+      for (int h = 0; h < HP; ++h) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) a = fmaf(x[uu][c][i], ur[c][h][i], a);
+        part[h] = a;
+      }
+      heads_reduce<HP>(part, lane);
+      const int h = lane >> (6 - LG);
+      if (tt < t1 && (lane & ((64 >> LG) - 1)) == 0 && h < H)
+        s[((size_t)b * N + tt) * H + h] = part[0];
+    }
+  }
+}
+
+// w[b,n] = (1/H) sum_h exp(s[b,n,h] - max_h) / sum_n exp(s[b,n,h] - max_h).
+// One workgroup per sample; s of one sample (N*H*4 bytes) is L2-resident, so the three
+// passes re-read it from cache.
+template <int HP>
+__global__ void __launch_bounds__(SC_THREADS)
+attn_weights_kernel(const float* __restrict__ s, int N, int H, float* __restrict__ w) {
+  __shared__ float red[SC_WAVES][HP];
+  __shared__ float stat[2][HP];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* sb = s + (size_t)b * N * H;
+  float m[HP];
+#pragma unroll
+  for (int h = 0; h < HP; ++h) m[h] = -INFINITY;
+  for (int n = tid; n < N; n += SC_THREADS)
+#pragma unroll
+    for (int h = 0; h < HP; ++h)
+      if (h < H) m[h] = fmaxf(m[h], sb[(size_t)n * H + h]);
+#pragma unroll
+  for (int h = 0; h < HP; ++h) {
+    const float v = wave_max(m[h]);
+    if (lane == 0) red[wave][h] = v;
+  }
+  __syncthreads();
+  if (tid < HP) {
+    float v = red[0][tid];
+    for (int i = 1; i < SC_WAVES; ++i) v = fmaxf(v, red[i][tid]);
+    stat[0][tid] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < HP; ++h) m[h] = stat[0][h];
+  float z[HP];
+#pragma unroll
+  for (int h = 0; h < HP; ++h) z[h] = 0.f;
+  for (int n = tid; n < N; n += SC_THREADS)
+#pragma unroll
+    for (int h = 0; h < HP; ++h)
+      if (h < H) z[h] += expf(sb[(size_t)n * H + h] - m[h]);
+#pragma unroll
+  for (int h = 0; h < HP; ++h) {
+    const float v = wave_sum(z[h]);
+    if (lane == 0) red[wave][h] = v;
+  }
+  __syncthreads();
+  if (tid < HP) {
+    float v = red[0][tid];
+    for (int i = 1; i < SC_WAVES; ++i) v += red[i][tid];
+    stat[1][tid] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < HP; ++h) z[h] = stat[1][h];
+  for (int n = tid; n < N; n += SC_THREADS) {
+    float a = 0.f;
+#pragma unroll
+    for (int h = 0; h < HP; ++h)
+      if (h < H) a += expf(sb[(size_t)n * H + h] - m[h]) / z[h];
+    w[(size_t)b * N + n] = a / (float)H;
+  }
+}
+
+inline int pad_heads(int H) {
+  int p = 1;
+  while (p < H) p <<= 1;
+  return p;
+}
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" int vqaf_fold_query(const void* q, const void* in_proj_weight, const void* in_proj_bias,
+                               int B, int D, int H, int dtype, int w_dtype, float* qproj_ws,
+                               float* u, vqaf_stream_t stream) {
+  VQAF_REQUIRE(q && in_proj_weight && in_proj_bias && qproj_ws && u, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(w_dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(B > 0 && D > 0 && H > 0 && D % H == 0, VQAF_E_SHAPE);
+  const int dh = D / H;
+  // qproj (B,D) = q Wq^T + bq
+  int rc = vqaf_gemm_f32(q, dtype, 0, D, 1, in_proj_weight, w_dtype, 0, 1, D, in_proj_bias, w_dtype,
+                         0, qproj_ws, 0, D, 1, B, D, D, 1.0f, 0, stream);
+  if (rc != VQAF_OK) return rc;
+  // u[b,h,:] = (1/sqrt(dh)) * qproj[b, h*dh:(h+1)*dh] @ Wk[h*dh:(h+1)*dh, :]
+  const size_t esz = vqaf_esize(w_dtype);
+  const void* wk = reinterpret_cast<const unsigned char*>(in_proj_weight) + (size_t)D * D * esz;
+  return vqaf_gemm_f32(qproj_ws, VQAF_F32, dh, D, 1, wk, w_dtype, (long)dh * D, D, 1, nullptr, 0, 0,
+                       u, D, (long)H * D, H, B, D, dh, 1.0f / sqrtf((float)dh), 0, stream);
+}
+
+extern "C" int vqaf_head_scores(const void* seq, const float* u, int B, int N, int D, int H,
+                                int dtype, float* s, vqaf_stream_t stream) {
+  VQAF_REQUIRE(seq && u && s, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(B > 0 && N > 0 && D > 0 && H > 0 && B <= 65535, VQAF_E_SHAPE);
+  VQAF_REQUIRE(D % 8 == 0 && vqaf_aligned16(seq) && vqaf_aligned16(u), VQAF_E_ALIGN);
+  const int HP = pad_heads(H);
+  const int CH = (D + 511) / 512;
+  VQAF_REQUIRE(HP * CH <= 16 && CH <= 2, VQAF_E_SHAPE);  // register budget of the u slice
+  int tokb = 64;
+  if ((long)B * ((N + 63) / 64) < 512) tokb = 32;
+  if ((long)B * ((N + 31) / 32) < 512) tokb = 16;
+  const dim3 grid((N + tokb - 1) / tokb, B), block(SC_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  const bool bf = dtype == VQAF_BF16;
+#define VQAF_HS(HPv, CHv)                                                                       \
+  do {                                                                                          \
+    if (bf) hipLaunchKernelGGL((head_scores_kernel<true, HPv, CHv>), grid, block, 0, st, seq, u, \
+                               N, D, H, tokb, s);                                               \
+    else hipLaunchKernelGGL((head_scores_kernel<false, HPv, CHv>), grid, block, 0, st, seq, u,   \
+                            N, D, H, tokb, s);                                                  \
+  } while (0)
+  if (CH == 1) {
+    switch (HP) {
+      case 1: VQAF_HS(1, 1); break;
+      case 2: VQAF_HS(2, 1); break;
+      case 4: VQAF_HS(4, 1); break;
+      case 8: VQAF_HS(8, 1); break;
+      default: VQAF_HS(16, 1); break;
+    }
+  } else {
+    switch (HP) {
+      case 1: VQAF_HS(1, 2); break;
+      case 2: VQAF_HS(2, 2); break;
+      case 4: VQAF_HS(4, 2); break;
+      default: VQAF_HS(8, 2); break;
+    }
+  }
+#undef VQAF_HS
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_attn_weights(const float* s, int B, int N, int H, float* w,
+                                 vqaf_stream_t stream) {
+  VQAF_REQUIRE(s && w, VQAF_E_NULL);
+  VQAF_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 16, VQAF_E_SHAPE);
+  const int HP = pad_heads(H);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(B), block(SC_THREADS);
+  switch (HP) {
+    case 1: hipLaunchKernelGGL(attn_weights_kernel<1>, grid, block, 0, st, s, N, H, w); break;
+    case 2: hipLaunchKernelGGL(attn_weights_kernel<2>, grid, block, 0, st, s, N, H, w); break;
+    case 4: hipLaunchKernelGGL(attn_weights_kernel<4>, grid, block, 0, st, s, N, H, w); break;
+    case 8: hipLaunchKernelGGL(attn_weights_kernel<8>, grid, block, 0, st, s, N, H, w); break;
+    default: hipLaunchKernelGGL(attn_weights_kernel<16>, grid, block, 0, st, s, N, H, w); break;
+  }
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" size_t vqaf_score_workspace_bytes(int B, int N, int D, int H) {
+  if (B <= 0 || N <= 0 || D <= 0 || H <= 0) return 0;
+  return align256((size_t)B * D * 4) + align256((size_t)B * H * D * 4) +
+         align256((size_t)B * N * H * 4);
+}
+
+extern "C" int vqaf_score(const void* q, const void* seq, const void* in_proj_weight,
+                          const void* in_proj_bias, int B, int N, int D, int H, int dtype,
+                          int w_dtype, void* workspace, size_t workspace_bytes, float* w,
+                          vqaf_stream_t stream) {
+  VQAF_REQUIRE(workspace != nullptr && w != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(B > 0 && N > 0 && D > 0 && H > 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(workspace_bytes >= vqaf_score_workspace_bytes(B, N, D, H), VQAF_E_SHAPE);
+  VQAF_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, VQAF_E_ALIGN);
+  unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+  float* qproj = reinterpret_cast<float*>(ws);
+  float* u = reinterpret_cast<float*>(ws + align256((size_t)B * D * 4));
+  float* s = reinterpret_cast<float*>(ws + align256((size_t)B * D * 4) + align256((size_t)B * H * D * 4));
+  int rc = vqaf_fold_query(q, in_proj_weight, in_proj_bias, B, D, H, dtype, w_dtype, qproj, u, stream);
+  if (rc != VQAF_OK) return rc;
+  rc = vqaf_head_scores(seq, u, B, N, D, H, dtype, s, stream);
+  if (rc != VQAF_OK) return rc;
+  return vqaf_attn_weights(s, B, N, H, w, stream);
+}

@@ -1,0 +1,168 @@
+// Keep-index selection: full per-row ranking by a bitonic network in LDS, adversarial index
+// mixing, and the device-side RNG counter.
+//
+// One workgroup ranks one row.  Every element becomes a 64-bit key
+//     (order-preserving image of the f32 weight) << 32 | (0xFFFFFFFF - index)
+// so keys are distinct and a descending sort yields (weight desc, index asc); rows are padded
+// to a power of two with key 0, which sorts below every real key.  The sorted prefix is the
+// keep list, the reversed tail the "bottom" list, so the two always partition [0,N).
+#include "common.h"
+
+namespace {
+
+constexpr int TK_MAX_N = 4096;
+
+__device__ __forceinline__ unsigned int order_key(float w) {
+  unsigned int u = __float_as_uint(w);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;  // NaN ranks above +inf
+  if (u == 0x80000000u) u = 0u;                             // -0 ties with +0
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Sorts keys[0..NP) descending; NP a power of two; all threads of the block take part.
+__device__ void bitonic_sort_desc(unsigned long long* keys, int NP) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int k = 2; k <= NP; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int p = tid; p < (NP >> 1); p += nt) {
+        const int t = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+        const int q = t | j;
+        const unsigned long long a = keys[t], c = keys[q];
+        const bool desc = (t & k) == 0;
+        if (desc ? (a < c) : (a > c)) {
+          keys[t] = c;
+          keys[q] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void topk_kernel(const float* __restrict__ w, int N, int K, int NP,
+                            int64_t* __restrict__ top, int64_t* __restrict__ bottom) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const float* wr = w + (size_t)b * N;
+  for (int i = tid; i < NP; i += nt)
+    keys[i] = (i < N) ? (((unsigned long long)order_key(wr[i]) << 32) |
+                         (unsigned long long)(0xffffffffu - (unsigned int)i))
+                      : 0ull;
+  __syncthreads();
+  bitonic_sort_desc(keys, NP);
+  const int R = N - K;
+  for (int r = tid; r < N; r += nt) {
+    const int64_t i = (int64_t)(0xffffffffu - (unsigned int)keys[r]);
+    if (r < K) top[(size_t)b * K + r] = i;
+    else if (bottom != nullptr) bottom[(size_t)b * R + (N - 1 - r)] = i;
+  }
+}
+
+__global__ void adv_swap_kernel(int64_t* __restrict__ top, const int64_t* __restrict__ bottom,
+                                const int64_t* __restrict__ pos, const int64_t* __restrict__ src,
+                                int K, int R, int k_adv) {
+  const int b = blockIdx.x;
+  for (int j = threadIdx.x; j < k_adv; j += blockDim.x) {
+    const int64_t p = pos[(size_t)b * k_adv + j], s = src[(size_t)b * k_adv + j];
+    if (p >= 0 && p < K && s >= 0 && s < R) top[(size_t)b * K + p] = bottom[(size_t)b * R + s];
+  }
+}
+
+// Random k_adv-prefix of a uniform permutation of [0,M): rank M random 51-bit keys (ties are
+// broken by position, probability ~ M^2 / 2^52) and keep the first k_adv positions.
+__device__ void random_prefix(unsigned long long* keys, int M, int NP, unsigned long long seed,
+                              unsigned long long counter, unsigned long long stream_id) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < NP; i += nt) {
+    unsigned long long key = 0ull;
+    if (i < M) {
+      const Philox4 r = philox4x32_10(seed, stream_id * (unsigned long long)TK_MAX_N + i, counter);
+      const unsigned long long r51 = (((unsigned long long)r.x << 32) | r.y) >> 13;
+      key = (1ull << 63) | (r51 << 12) | (unsigned long long)(TK_MAX_N - 1 - i);  // above padding
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  bitonic_sort_desc(keys, NP);
+}
+
+__global__ void adv_swap_random_kernel(int64_t* __restrict__ top, const int64_t* __restrict__ bottom,
+                                       int K, int R, int k_adv, int NPK, int NPR,
+                                       const uint64_t* __restrict__ rng_state,
+                                       int64_t* __restrict__ pos_out, int64_t* __restrict__ src_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  __shared__ int s_pos[TK_MAX_N / 2];  // k_adv <= K/1 but bounded by host check
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const unsigned long long seed = rng_state[0], counter = rng_state[1];
+  // positions inside the keep list
+  random_prefix(keys, K, NPK, seed, counter, 2ull * b);
+  for (int j = tid; j < k_adv; j += nt) s_pos[j] = TK_MAX_N - 1 - (int)(keys[j] & (TK_MAX_N - 1));
+  __syncthreads();
+  // sources inside the bottom list
+  random_prefix(keys, R, NPR, seed, counter, 2ull * b + 1ull);
+  for (int j = tid; j < k_adv; j += nt) {
+    const int p = s_pos[j];
+    const int s = TK_MAX_N - 1 - (int)(keys[j] & (TK_MAX_N - 1));
+    top[(size_t)b * K + p] = bottom[(size_t)b * R + s];
+    if (pos_out != nullptr) pos_out[(size_t)b * k_adv + j] = p;
+    if (src_out != nullptr) src_out[(size_t)b * k_adv + j] = s;
+  }
+}
+
+__global__ void rng_advance_kernel(uint64_t* state, uint64_t delta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += delta;
+}
+
+inline int next_pow2(int n) {
+  int p = 64;
+  while (p < n) p <<= 1;
+  return p;
+}
+inline int sort_threads(int NP) {
+  int t = NP / 2;
+  if (t < 64) t = 64;
+  if (t > 1024) t = 1024;
+  return t;
+}
+
+}  // namespace
+
+extern "C" int vqaf_topk(const float* w, int B, int N, int K, int64_t* top, int64_t* bottom,
+                         vqaf_stream_t stream) {
+  VQAF_REQUIRE(w != nullptr && top != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(B > 0 && N > 0 && K > 0 && K <= N && N <= TK_MAX_N, VQAF_E_SHAPE);
+  const int NP = next_pow2(N);
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(sort_threads(NP)), (size_t)NP * 8,
+                     (hipStream_t)stream, w, N, K, NP, top, bottom);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_adv_swap(int64_t* top, const int64_t* bottom, const int64_t* pos,
+                             const int64_t* src, int B, int K, int R, int k_adv,
+                             vqaf_stream_t stream) {
+  VQAF_REQUIRE(top != nullptr && bottom != nullptr && pos != nullptr && src != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(B > 0 && K > 0 && R > 0 && k_adv > 0 && k_adv <= K && k_adv <= R, VQAF_E_SHAPE);
+  hipLaunchKernelGGL(adv_swap_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, top, bottom, pos,
+                     src, K, R, k_adv);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_adv_swap_random(int64_t* top, const int64_t* bottom, int B, int K, int R,
+                                    int k_adv, const uint64_t* rng_state, int64_t* pos_out,
+                                    int64_t* src_out, vqaf_stream_t stream) {
+  VQAF_REQUIRE(top != nullptr && bottom != nullptr && rng_state != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(B > 0 && K > 0 && R > 0 && k_adv > 0 && k_adv <= K && k_adv <= R, VQAF_E_SHAPE);
+  VQAF_REQUIRE(K <= TK_MAX_N && R <= TK_MAX_N && k_adv <= TK_MAX_N / 2, VQAF_E_SHAPE);
+  const int NPK = next_pow2(K), NPR = next_pow2(R);
+  const int NP = NPK > NPR ? NPK : NPR;
+  hipLaunchKernelGGL(adv_swap_random_kernel, dim3(B), dim3(sort_threads(NP)), (size_t)NP * 8,
+                     (hipStream_t)stream, top, bottom, K, R, k_adv, NPK, NPR, rng_state, pos_out,
+                     src_out);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_rng_advance(uint64_t* rng_state, uint64_t delta, vqaf_stream_t stream) {
+  VQAF_REQUIRE(rng_state != nullptr, VQAF_E_NULL);
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rng_state, delta);
+  VQAF_LAUNCH_CHECK();
+}

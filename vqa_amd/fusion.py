@@ -1,0 +1,187 @@
+"""Drop-in fusion modules: same classes, constructor arguments, attribute and parameter names
+as utils/fusion.py of the reference, running on the libvqafuse HIP kernels.
+
+    PrivacyAwareTokenPruning  utils/fusion.py:5-116
+    Concat                    utils/fusion.py:118-126
+    Attention                 utils/fusion.py:129-183
+    CoAttention               utils/fusion.py:186-275
+
+Differences a user can observe, all documented where they occur:
+  * tie order of equal attention weights is defined (weight desc, index asc); torch.topk leaves
+    it unspecified;
+  * random draws (adversarial positions, noise) come from a counter-based generator seeded by
+    torch's global seed, so the stream differs from torch.randperm / torch.normal (as the
+    reference's own CPU and GPU streams differ); pre-drawn tensors can be injected;
+  * tensors keep their storage dtype (a bf16 `seq` gives a bf16 result; the reference's
+    f32 mask/noise temporaries would silently promote it to f32); sums accumulate in f32.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class PrivacyAwareTokenPruning(nn.Module):
+    """Attention-score token pruning with adversarial index mixing, noise and a mix token.
+
+    Same hyper-parameters and defaults as utils/fusion.py:14-24.
+    """
+
+    def __init__(self, prune_ratio=0.5, mixup_alpha=0.05, adversarial_mix=True, adv_ratio=0.2,
+                 noise_injection=True, noise_scale=0.01, noise_type='gaussian'):
+        super().__init__()
+        self.prune_ratio = prune_ratio
+        self.mixup_alpha = mixup_alpha
+        self.adversarial_mix = adversarial_mix
+        self.adv_ratio = adv_ratio
+        self.noise_injection = noise_injection
+        self.noise_scale = noise_scale
+        self.noise_type = noise_type
+        self.rng: Optional[ops.PhiloxState] = None  # None -> per-device default stream
+        self.last_indices: Optional[torch.Tensor] = None
+
+    # -- index selection: utils/fusion.py:35-65 ------------------------------------------------
+    @torch.no_grad()
+    def select(self, attn_weights: torch.Tensor, n_tokens: int,
+               replace_positions: Optional[torch.Tensor] = None,
+               random_bottom: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Keep indices (B,K) int64.  `replace_positions` / `random_bottom` (B,k_adv) inject the
+        draws of utils/fusion.py:59,62 (positions into the keep list / into the bottom list)."""
+        if attn_weights.dim() == 3:
+            attn_weights = attn_weights.squeeze(1)
+        k = ops.keep_count(n_tokens, self.prune_ratio)
+        remaining_k = n_tokens - k
+        top, bottom = ops.topk_indices(attn_weights, k, need_bottom=bool(self.adversarial_mix))
+        if self.adversarial_mix:
+            k_adv = ops.adv_count(k, self.adv_ratio)
+            # utils/fusion.py:57 -- the swap is skipped when fewer than k_adv tokens were dropped
+            if remaining_k >= k_adv:
+                if replace_positions is not None or random_bottom is not None:
+                    if replace_positions is None or random_bottom is None:
+                        raise ValueError("inject both replace_positions and random_bottom, or neither")
+                    ops.adv_swap_(top, bottom, replace_positions.to(torch.int64),
+                                  random_bottom.to(torch.int64))
+                else:
+                    ops.adv_swap_random_(top, bottom, k_adv, self.rng or ops.default_rng(top.device))
+        return top
+
+    def _noise_args(self, noise: Optional[torch.Tensor]):
+        if not self.noise_injection:
+            return None, None
+        if self.noise_type not in ('gaussian', 'uniform'):
+            raise ValueError(f"Unsupported noise type: {self.noise_type}")  # utils/fusion.py:111
+        if noise is not None:
+            return noise, None
+        return None, self.noise_type
+
+    def forward(self, seq, attn_weights, replace_positions=None, random_bottom=None, noise=None):
+        """seq (B,N,D), attn_weights (B,1,N) or (B,N) -> (B,K+1,D) ((B,K,D) if mixup_alpha <= 0)."""
+        B, N, D = seq.shape
+        idx = self.select(attn_weights, N, replace_positions, random_bottom)
+        self.last_indices = idx
+        noise_t, noise_type = self._noise_args(noise)
+        return ops.gather_mix(seq, idx, float(self.mixup_alpha), noise=noise_t, noise_type=noise_type,
+                              noise_scale=float(self.noise_scale), rng=self.rng)
+
+    def pool_spec(self, seq, attn_weights, replace_positions=None, random_bottom=None, noise=None):
+        """Arguments for ops.pruned_pool: the same pruning, consumed as a token mean."""
+        B, N, D = seq.shape
+        idx = self.select(attn_weights, N, replace_positions, random_bottom)
+        self.last_indices = idx
+        noise_t, noise_type = self._noise_args(noise)
+        return dict(seq=seq, idx=idx, alpha=float(self.mixup_alpha), noise=noise_t,
+                    noise_type=noise_type, noise_scale=float(self.noise_scale), rng=self.rng)
+
+
+class Concat(nn.Module):
+    """cat([v_global, q_global]) -- utils/fusion.py:118-126 (no kernel needed)."""
+
+    def __init__(self, v_dim=512, q_dim=512):
+        super().__init__()
+        self.output_dim = v_dim + q_dim
+
+    def forward(self, v_seq, v_global, q_seq, q_global):
+        return torch.cat([v_global, q_global], dim=1)
+
+
+def _scores(mha: nn.MultiheadAttention, query: torch.Tensor, seq: torch.Tensor) -> torch.Tensor:
+    return ops.attention_scores(query, seq, mha.in_proj_weight, mha.in_proj_bias, mha.num_heads)
+
+
+class Attention(nn.Module):
+    """text -> image attention with optional token pruning (utils/fusion.py:129-183)."""
+
+    def __init__(self, embed_dim=512, num_heads=8, use_pruning=False, prune_ratio=0.5,
+                 mixup_alpha=0.05, adversarial_mix=True, adv_ratio=0.2):
+        super().__init__()
+        self.attention = nn.MultiheadAttention(embed_dim, num_heads, batch_first=True)
+        self.output_dim = embed_dim * 2
+        self.use_pruning = use_pruning
+        self.fuse_pool = True  # skip materialising the pruned tokens (same result)
+        if use_pruning:
+            # utils/fusion.py:141-146 passes no noise arguments, so the class defaults apply
+            # (noise_injection=True, noise_scale=0.01, gaussian).
+            self.pruning = PrivacyAwareTokenPruning(prune_ratio=prune_ratio, mixup_alpha=mixup_alpha,
+                                                    adversarial_mix=adversarial_mix, adv_ratio=adv_ratio)
+
+    def forward(self, v_seq, v_global, q_seq, q_global, **inject):
+        if self.use_pruning:
+            w = _scores(self.attention, q_global, v_seq)
+            if self.fuse_pool:
+                attended_v = ops.pruned_pool([self.pruning.pool_spec(v_seq, w, **inject)], v_seq.dtype)
+            else:
+                attended_v = ops.mean_pool(self.pruning(v_seq, w, **inject))
+        else:
+            from .xattn import single_query_attention
+            attended_v = single_query_attention(self.attention, q_global, v_seq)
+        return torch.cat([attended_v, q_global.to(attended_v.dtype)], dim=1)
+
+
+class CoAttention(nn.Module):
+    """Co-attention with privacy-aware token pruning (utils/fusion.py:186-275)."""
+
+    def __init__(self, embed_dim=512, num_heads=8, use_pruning=False, prune_ratio=0.5,
+                 mixup_alpha=0.05, adversarial_mix=True, adv_ratio=0.2,
+                 noise_injection=True, noise_scale=0.01, noise_type='gaussian'):
+        super().__init__()
+        self.txt_to_vis_attn = nn.MultiheadAttention(embed_dim, num_heads, batch_first=True)
+        self.vis_to_txt_attn = nn.MultiheadAttention(embed_dim, num_heads, batch_first=True)
+        self.output_dim = embed_dim * 2
+        self.use_pruning = use_pruning
+        self.fuse_pool = True
+        if use_pruning:
+            self.v_pruning = PrivacyAwareTokenPruning(
+                prune_ratio=prune_ratio, mixup_alpha=mixup_alpha, adversarial_mix=adversarial_mix,
+                adv_ratio=adv_ratio, noise_injection=noise_injection, noise_scale=noise_scale,
+                noise_type=noise_type)
+            # text tokens never get noise (utils/fusion.py:216-224)
+            self.q_pruning = PrivacyAwareTokenPruning(
+                prune_ratio=prune_ratio, mixup_alpha=mixup_alpha, adversarial_mix=adversarial_mix,
+                adv_ratio=adv_ratio, noise_injection=False, noise_scale=0, noise_type=noise_type)
+
+    def forward(self, v_seq, v_global, q_seq, q_global, v_inject=None, q_inject=None):
+        """v_inject / q_inject: optional dicts(replace_positions=, random_bottom=, noise=) that
+        replay pre-drawn randomness in the vision / text pruning (parity tests)."""
+        v_inject = v_inject or {}
+        q_inject = q_inject or {}
+        if self.use_pruning:
+            v_w = _scores(self.txt_to_vis_attn, q_global, v_seq)      # utils/fusion.py:234-238
+            if self.fuse_pool:
+                v_spec = self.v_pruning.pool_spec(v_seq, v_w, **v_inject)
+                q_w = _scores(self.vis_to_txt_attn, v_global, q_seq)  # utils/fusion.py:243-247
+                q_spec = self.q_pruning.pool_spec(q_seq, q_w, **q_inject)
+                return ops.pruned_pool([v_spec, q_spec], v_seq.dtype)  # :253-254, :274
+            v_pruned = self.v_pruning(v_seq, v_w, **v_inject)         # :240
+            q_w = _scores(self.vis_to_txt_attn, v_global, q_seq)
+            q_pruned = self.q_pruning(q_seq, q_w, **q_inject)         # :249
+            attended_v = ops.mean_pool(v_pruned)
+            attended_q = ops.mean_pool(q_pruned)
+        else:
+            from .xattn import single_query_attention
+            attended_v = single_query_attention(self.txt_to_vis_attn, q_global, v_seq)  # :257-261
+            attended_q = single_query_attention(self.vis_to_txt_attn, v_global, q_seq)  # :264-268
+        return torch.cat([attended_v, attended_q.to(attended_v.dtype)], dim=1)

@@ -1,0 +1,302 @@
+"""Tensor-level wrappers over the libvqafuse C ABI.
+
+Every function here takes and returns torch tensors that live on a HIP device, enqueues the
+kernels on torch's current stream and never synchronises with the host.  torch is used for
+device memory, streams and autograd bookkeeping only; the arithmetic is in the kernels.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, dtype_code, load, ptr, stream_ptr
+
+
+# --------------------------------------------------------------------------------------------
+# Device-side counter-based RNG state {seed, counter}
+# --------------------------------------------------------------------------------------------
+class PhiloxState:
+    """Two 64-bit words in device memory: {seed, counter}.
+
+    Kernels that draw random numbers read the pair and address each draw by
+    (seed, counter, element); ``advance()`` bumps the counter on the stream, so a captured HIP
+    graph draws fresh numbers on every replay.
+    """
+
+    def __init__(self, device: torch.device, seed: Optional[int] = None, stream_salt: int = 0):
+        if seed is None:
+            seed = torch.initial_seed()
+        self.seed = (int(seed) + 0x9E3779B97F4A7C15 * int(stream_salt)) & 0xFFFFFFFFFFFFFFFF
+        signed = self.seed - (1 << 64) if self.seed >= (1 << 63) else self.seed
+        self.state = torch.tensor([signed, 0], dtype=torch.int64, device=device)
+
+    def advance(self, delta: int = 1) -> None:
+        check(load().vqaf_rng_advance(ptr(self.state), delta, stream_ptr(self.state.device)),
+              "vqaf_rng_advance")
+
+
+_default_states: dict = {}
+
+
+def default_rng(device: torch.device) -> PhiloxState:
+    """Per-device state seeded from torch's global seed (re-made after torch.manual_seed)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    seed = torch.initial_seed()
+    st = _default_states.get(key)
+    if st is None or st[0] != seed:
+        st = (seed, PhiloxState(device, seed))
+        _default_states[key] = st
+    return st[1]
+
+
+def _noise_kind(noise_type: Optional[str]) -> int:
+    if noise_type is None:
+        return _lib.NOISE_NONE
+    if noise_type == "gaussian":
+        return _lib.NOISE_GAUSSIAN
+    if noise_type == "uniform":
+        return _lib.NOISE_UNIFORM
+    # same message as utils/fusion.py:111 of the reference
+    raise ValueError(f"Unsupported noise type: {noise_type}")
+
+
+# --------------------------------------------------------------------------------------------
+# Scoring and selection (no gradients flow through these: the weights only feed indices)
+# --------------------------------------------------------------------------------------------
+@torch.no_grad()
+def attention_scores(q: torch.Tensor, seq: torch.Tensor, in_proj_weight: torch.Tensor,
+                     in_proj_bias: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """Head-averaged single-query attention weights (B,N) f32; see vqaf_score."""
+    B, N, D = seq.shape
+    seq = seq.contiguous()
+    q = q.reshape(B, D).to(seq.dtype).contiguous()
+    w_ = in_proj_weight.detach().contiguous()
+    b_ = in_proj_bias.detach().to(w_.dtype).contiguous()
+    lib = load()
+    nbytes = lib.vqaf_score_workspace_bytes(B, N, D, num_heads)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=seq.device)
+    out = torch.empty(B, N, dtype=torch.float32, device=seq.device)
+    check(lib.vqaf_score(ptr(q), ptr(seq), ptr(w_), ptr(b_), B, N, D, num_heads, dtype_code(seq),
+                         dtype_code(w_), ptr(ws), nbytes, ptr(out), stream_ptr(seq.device)),
+          "vqaf_score")
+    return out
+
+
+@torch.no_grad()
+def topk_indices(w: torch.Tensor, k: int, need_bottom: bool = True
+                 ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """(top (B,k) int64 weight-descending, bottom (B,N-k) int64 weight-ascending)."""
+    if w.dim() == 3:
+        w = w.squeeze(1)
+    w = w.to(torch.float32).contiguous()
+    B, N = w.shape
+    top = torch.empty(B, k, dtype=torch.int64, device=w.device)
+    bottom = torch.empty(B, N - k, dtype=torch.int64, device=w.device) if (need_bottom and N > k) else None
+    check(load().vqaf_topk(ptr(w), B, N, k, ptr(top), ptr(bottom), stream_ptr(w.device)), "vqaf_topk")
+    return top, bottom
+
+
+@torch.no_grad()
+def adv_swap_(top: torch.Tensor, bottom: torch.Tensor, pos: torch.Tensor, src: torch.Tensor) -> None:
+    B, K = top.shape
+    R = bottom.shape[1]
+    k_adv = pos.shape[1]
+    check(load().vqaf_adv_swap(ptr(top), ptr(bottom), ptr(pos.contiguous()), ptr(src.contiguous()),
+                               B, K, R, k_adv, stream_ptr(top.device)), "vqaf_adv_swap")
+
+
+@torch.no_grad()
+def adv_swap_random_(top: torch.Tensor, bottom: torch.Tensor, k_adv: int, rng: PhiloxState,
+                     record: bool = False):
+    B, K = top.shape
+    R = bottom.shape[1]
+    pos = src = None
+    if record:
+        pos = torch.empty(B, k_adv, dtype=torch.int64, device=top.device)
+        src = torch.empty(B, k_adv, dtype=torch.int64, device=top.device)
+    check(load().vqaf_adv_swap_random(ptr(top), ptr(bottom), B, K, R, k_adv, ptr(rng.state),
+                                      ptr(pos), ptr(src), stream_ptr(top.device)),
+          "vqaf_adv_swap_random")
+    rng.advance()
+    return pos, src
+
+
+# --------------------------------------------------------------------------------------------
+# Gather + noise + mix token (differentiable w.r.t. seq)
+# --------------------------------------------------------------------------------------------
+class _GatherMix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seq, idx, noise, noise_kind, noise_scale, rng_state, alpha, out_dtype):
+        B, N, D = seq.shape
+        K = idx.shape[1]
+        seq_c = seq.contiguous()
+        idx_c = idx.contiguous()
+        kout = K + (1 if alpha > 0 else 0)
+        out = torch.empty(B, kout, D, dtype=out_dtype, device=seq.device)
+        noise_c = noise.to(torch.float32).contiguous() if noise is not None else None
+        check(load().vqaf_gather_mix(ptr(seq_c), ptr(idx_c), ptr(noise_c), noise_kind,
+                                     float(noise_scale), ptr(rng_state), float(alpha), B, N, K, D,
+                                     dtype_code(seq_c), dtype_code(out), ptr(out),
+                                     stream_ptr(seq.device)), "vqaf_gather_mix")
+        ctx.save_for_backward(idx_c)
+        ctx.meta = (B, N, K, D, float(alpha), seq.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx_c,) = ctx.saved_tensors
+        B, N, K, D, alpha, sdt = ctx.meta
+        g = grad_out.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        grad_seq = torch.empty(B, N, D, dtype=sdt, device=g.device)
+        check(load().vqaf_gather_mix_bwd(ptr(g), ptr(idx_c), alpha, B, N, K, D, dtype_code(g),
+                                         dtype_code(grad_seq), ptr(grad_seq), stream_ptr(g.device)),
+              "vqaf_gather_mix_bwd")
+        return grad_seq, None, None, None, None, None, None, None
+
+
+def gather_mix(seq: torch.Tensor, idx: torch.Tensor, alpha: float, noise: Optional[torch.Tensor] = None,
+               noise_type: Optional[str] = None, noise_scale: float = 0.0,
+               rng: Optional[PhiloxState] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """out (B,K+1,D) (or (B,K,D) if alpha <= 0); see vqaf_gather_mix."""
+    kind = _noise_kind(noise_type) if noise is None else _lib.NOISE_NONE
+    state = None
+    if kind != _lib.NOISE_NONE:
+        rng = rng or default_rng(seq.device)
+        state = rng.state
+    out = _GatherMix.apply(seq, idx, noise, kind, noise_scale, state, alpha, out_dtype or seq.dtype)
+    if kind != _lib.NOISE_NONE:
+        rng.advance()
+    return out
+
+
+class _MeanPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, M, D = x.shape
+        xc = x.contiguous()
+        out = torch.empty(B, D, dtype=x.dtype, device=x.device)
+        check(load().vqaf_mean_pool(ptr(xc), B, M, D, dtype_code(xc), ptr(out), D, 0, dtype_code(out),
+                                    stream_ptr(x.device)), "vqaf_mean_pool")
+        ctx.meta = (B, M, D, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        B, M, D, dt = ctx.meta
+        g = grad_out.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        gx = torch.empty(B, M, D, dtype=dt, device=g.device)
+        check(load().vqaf_mean_pool_bwd(ptr(g), D, 0, dtype_code(g), B, M, D, dtype_code(gx), ptr(gx),
+                                        stream_ptr(g.device)), "vqaf_mean_pool_bwd")
+        return gx
+
+
+def mean_pool(x: torch.Tensor) -> torch.Tensor:
+    """x.mean(dim=1) for (B,M,D) tokens."""
+    return _MeanPool.apply(x)
+
+
+class _PrunedPool(torch.autograd.Function):
+    """fused[:, off:off+D] = mean_j prune(seq_m, idx_m)[:, j, :] for each modality m, without
+    writing the pruned token tensors.  Inputs: a list of (seq, idx, alpha, noise, kind, scale,
+    rng_state) flattened; output (B, sum D_m)."""
+
+    @staticmethod
+    def forward(ctx, n_mod, out_dtype, *flat):
+        mods = [flat[i * 7:(i + 1) * 7] for i in range(n_mod)]
+        B = mods[0][0].shape[0]
+        dev = mods[0][0].device
+        widths = [m[0].shape[2] for m in mods]
+        ld = sum(widths)
+        out = torch.empty(B, ld, dtype=out_dtype, device=dev)
+        lib = load()
+        col0 = 0
+        saved, metas = [], []
+        for (seq, idx, alpha, noise, kind, scale, state), D in zip(mods, widths):
+            _, N, _ = seq.shape
+            K = idx.shape[1]
+            seq_c, idx_c = seq.contiguous(), idx.contiguous()
+            noise_c = noise.to(torch.float32).contiguous() if noise is not None else None
+            check(lib.vqaf_gather_mix_pool(ptr(seq_c), ptr(idx_c), ptr(noise_c), kind, float(scale),
+                                           ptr(state), float(alpha), B, N, K, D, dtype_code(seq_c),
+                                           ptr(out), ld, col0, dtype_code(out), stream_ptr(dev)),
+                  "vqaf_gather_mix_pool")
+            if state is not None:  # next consumer gets a fresh stream
+                check(lib.vqaf_rng_advance(ptr(state), 1, stream_ptr(dev)), "vqaf_rng_advance")
+            saved.append(idx_c)
+            metas.append((N, K, D, float(alpha), seq.dtype, col0))
+            col0 += D
+        ctx.save_for_backward(*saved)
+        ctx.metas = metas
+        ctx.B, ctx.ld, ctx.n_mod = B, ld, n_mod
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = grad_out.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        lib = load()
+        grads = [None, None]
+        for i, (idx_c, (N, K, D, alpha, sdt, col0)) in enumerate(zip(ctx.saved_tensors, ctx.metas)):
+            gs = None
+            if ctx.needs_input_grad[2 + 7 * i]:
+                gs = torch.empty(ctx.B, N, D, dtype=sdt, device=g.device)
+                check(lib.vqaf_gather_mix_pool_bwd(ptr(g), ctx.ld, col0, dtype_code(g), ptr(idx_c),
+                                                   alpha, ctx.B, N, K, D, dtype_code(gs), ptr(gs),
+                                                   stream_ptr(g.device)), "vqaf_gather_mix_pool_bwd")
+            grads.extend([gs, None, None, None, None, None, None])
+        return tuple(grads)
+
+
+def pruned_pool(mods, out_dtype: torch.dtype) -> torch.Tensor:
+    """mods: list of dicts(seq, idx, alpha, noise, noise_type, noise_scale, rng)."""
+    flat = []
+    for m in mods:
+        kind = _noise_kind(m.get("noise_type")) if m.get("noise") is None else _lib.NOISE_NONE
+        state = None
+        if kind != _lib.NOISE_NONE:
+            state = (m.get("rng") or default_rng(m["seq"].device)).state
+        flat.extend([m["seq"], m["idx"], m["alpha"], m.get("noise"), kind, m.get("noise_scale", 0.0), state])
+    return _PrunedPool.apply(len(mods), out_dtype, *flat)
+
+
+# --------------------------------------------------------------------------------------------
+# Small helpers used by the DP-SGD engine and the MIA scorer
+# --------------------------------------------------------------------------------------------
+@torch.no_grad()
+def ce_conf(logits: torch.Tensor, targets: Optional[torch.Tensor] = None, want_loss: bool = True,
+            want_conf: bool = True, want_pred: bool = False, grad_scale: Optional[float] = None):
+    """Per-sample cross-entropy, max-softmax confidence, argmax and (optionally) the gradient of
+    grad_scale * sum_i CE_i w.r.t. the logits.  Returns (loss, conf, pred, grad)."""
+    B, C = logits.shape
+    lg = logits.contiguous()
+    dev = lg.device
+    loss = torch.empty(B, dtype=torch.float32, device=dev) if (want_loss and targets is not None) else None
+    conf = torch.empty(B, dtype=torch.float32, device=dev) if want_conf else None
+    pred = torch.empty(B, dtype=torch.int64, device=dev) if want_pred else None
+    grad = torch.empty(B, C, dtype=torch.float32, device=dev) if grad_scale is not None else None
+    tg = targets.to(torch.int64).contiguous() if targets is not None else None
+    check(load().vqaf_ce_conf(ptr(lg), ptr(tg), B, C, dtype_code(lg), ptr(loss), ptr(conf), ptr(pred),
+                              ptr(grad), float(grad_scale or 0.0), stream_ptr(dev)), "vqaf_ce_conf")
+    return loss, conf, pred, grad
+
+
+def keep_count(n_tokens: int, prune_ratio: float) -> int:
+    """k = max(1, int(N * (1 - prune_ratio))) in Python double arithmetic (utils/fusion.py:41)."""
+    return max(1, int(n_tokens * (1 - prune_ratio)))
+
+
+def adv_count(k: int, adv_ratio: float) -> int:
+    """k_adv = max(1, int(k * adv_ratio)) (utils/fusion.py:54)."""
+    return max(1, int(k * adv_ratio))
+
+
+def sqrt_dh(embed_dim: int, num_heads: int) -> float:
+    return math.sqrt(embed_dim // num_heads)
