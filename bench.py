@@ -1,0 +1,266 @@
+"""Benchmark of the DP-SGD-trained fusion hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one DP-SGD training step of the fusion + classifier path on token-level synthetic
+COCO-QA-shaped inputs already resident in HBM (encoders are outside the hot path):
+zero_grad -> CoAttention(pruning, keep 0.5, adversarial mixing) forward -> classifier forward ->
+mean CE -> backward (classifier input gradients, fusion input gradients) -> per-sample norms,
+clip (C = 1.0), clipped sums, Gaussian noise (sigma = 1.0), RCCL all-reduce, AdamW step.
+Logical batch 1024 is sharded over the ranks (strong scaling, BASELINE.json configs[2]).
+
+Rank 0 prints ONE JSON line: whole-job samples/s plus a `roofline` object for the prune+mix
+kernel (timed live with stream events inside the timed region), a `cpu_baseline` object (the
+oracle, i.e. the reference's op sequence, timed on the host cores on a bounded sample) and the
+prune+mix GB/s sweep of configs[3].
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak; the measured copy ceiling is ~6.3 TB/s
+
+LOGICAL_BATCH = 1024
+N_VIS, N_TXT, D, C = 197, 30, 512, 430
+KEEP = 0.5
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=LOGICAL_BATCH, help="logical (whole-job) batch")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=64)
+    return ap.parse_args()
+
+
+class Probe:
+    """Stream-event pairs around one named kernel launch (torch's current stream is the stream
+    the C ABI launches on)."""
+
+    def __init__(self, name):
+        self.name, self.pairs, self.enabled, self._open = name, [], False, None
+
+    def __call__(self, name, phase):
+        if not self.enabled or name != self.name:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if phase == "begin":
+            self._open = ev
+        else:
+            self.pairs.append((self._open, ev))
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / max(1, len(self.pairs))
+
+
+def build_job(dev, local_b, dtype, rank):
+    from vqa_amd import dp, fusion
+    torch.manual_seed(42)  # the reference's seed (train.py:19): identical parameters on all ranks
+    fus = fusion.CoAttention(embed_dim=D, num_heads=8, use_pruning=True, prune_ratio=1 - KEEP,
+                             mixup_alpha=0.05, adversarial_mix=True, adv_ratio=0.2,
+                             noise_injection=False).to(dev)
+    cls = nn.Sequential(nn.Linear(2 * D, 2048), nn.BatchNorm1d(2048), nn.ReLU(), nn.Dropout(0.3),
+                        nn.Linear(2048, 1024), nn.BatchNorm1d(1024), nn.ReLU(), nn.Linear(1024, C))
+    cls = dp.ModuleValidator.fix(cls).to(dev)
+    if dtype == torch.bfloat16:
+        fus = fus.to(torch.bfloat16)
+    gsm = dp.GradSampleModule(cls)
+    inner = torch.optim.AdamW(cls.parameters(), lr=1e-4, weight_decay=0.01)
+    opt = dp.DPOptimizer(inner, gsm, noise_multiplier=1.0, max_grad_norm=1.0,
+                         expected_batch_size=LOGICAL_BATCH, seed=1234)
+    main_opt = torch.optim.AdamW(fus.parameters(), lr=1e-4, weight_decay=0.01)
+    # four rotating input sets: > 256 MiB of tokens in total, so no set survives in the
+    # Infinity Cache from one use to the next
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    sets = []
+    for _ in range(4):
+        v = torch.randn(local_b, N_VIS, D, device=dev, generator=gen).to(dtype).requires_grad_()
+        q = torch.randn(local_b, N_TXT, D, device=dev, generator=gen).to(dtype).requires_grad_()
+        y = torch.randint(0, C, (local_b,), device=dev, generator=gen)
+        sets.append((v, v.detach().float().mean(1).to(dtype), q, q.detach().float().mean(1).to(dtype), y))
+    return fus, gsm, opt, main_opt, sets
+
+
+def make_step(fus, gsm, opt, main_opt, sets):
+    from vqa_amd import ops
+
+    def step(i):
+        v, vg, q, qg, y = sets[i % len(sets)]
+        v.grad = None
+        q.grad = None
+        main_opt.zero_grad()
+        opt.zero_grad()
+        fused = fus(v, vg, q, qg)
+        logits = gsm(fused)
+        loss = ops.cross_entropy_mean(logits, y)
+        loss.backward()
+        main_opt.step()
+        opt.step()
+        return loss
+
+    return step
+
+
+def prune_mix_sweep(dev, dtype):
+    """configs[3]: N = 577 vision tokens, B = 128, keep-ratio sweep; the module-boundary op
+    PrivacyAwareTokenPruning.forward (top-k + gather + mix token) with its algorithmic bytes
+    N*D*s + N*4 + (K+1)*D*s + K*8 per sample."""
+    from vqa_amd import ops
+    B, N = 128, 577
+    s = 2 if dtype == torch.bfloat16 else 4
+    gen = torch.Generator(device=dev).manual_seed(7)
+    seqs = [torch.randn(B, N, D, device=dev, generator=gen).to(dtype) for _ in range(6)]
+    w = torch.rand(B, N, device=dev, generator=gen)
+    out = {}
+    for keep in (0.25, 0.5, 0.75, 0.9):
+        K = ops.keep_count(N, 1 - keep)
+        for _ in range(3):
+            idx, _b = ops.topk_indices(w, K, need_bottom=False)
+            ops.gather_mix(seqs[0], idx, 0.05)
+        reps = 24
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for r in range(reps):
+            idx, _b = ops.topk_indices(w, K, need_bottom=False)
+            ops.gather_mix(seqs[r % len(seqs)], idx, 0.05)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        nbytes = B * (N * D * s + N * 4 + (K + 1) * D * s + K * 8)
+        out[f"keep_{keep}"] = {"ms": round(ms, 5), "GB/s": round(nbytes / ms / 1e6, 1),
+                               "frac_of_8TBs": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def cpu_baseline(sample):
+    """The oracle (reference op sequence: MHA weights -> topk -> gather -> masked mean -> cat ->
+    mean; per-sample gradients by vmap(grad) -> norms -> clip -> sum -> noise -> scale) on the
+    host cores, fp32, one bounded batch."""
+    from oracle import dp_oracle as do
+    from oracle import fusion_oracle as fo
+    from oracle import inputs as gi
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    B = sample
+    v_seq, v_global = gi.tokens(1, B, N_VIS)
+    q_seq, q_global = gi.tokens(2, B, N_TXT)
+    t2v, v2t = gi.mha_params(3), gi.mha_params(7)
+    y = gi.labels(5, B, C)
+    cls = do.make_classifier(2 * D, 1024, C).eval()
+    k = fo.keep_count(N_VIS, 1 - KEEP)
+    kq = fo.keep_count(N_TXT, 1 - KEEP)
+    vd = gi.adversarial_draws(11, B, k, N_VIS - k, fo.adv_count(k, 0.2))
+    qd = gi.adversarial_draws(12, B, kq, N_TXT - kq, fo.adv_count(kq, 0.2))
+
+    def one():
+        vs, qs = v_seq.clone().requires_grad_(), q_seq.clone().requires_grad_()
+        fused, _, _ = fo.co_attention_pruned(vs, v_global, qs, q_global,
+                                             (t2v["in_proj_weight"], t2v["in_proj_bias"]),
+                                             (v2t["in_proj_weight"], v2t["in_proj_bias"]),
+                                             v_draws=vd, q_draws=qd)
+        f = fused.detach().requires_grad_()
+        nn.functional.cross_entropy(cls(f), y).backward()
+        fused.backward(f.grad)  # input gradients of the fusion
+        do.dp_step(cls, fused.detach(), y, 1.0, 1.0, LOGICAL_BATCH)
+
+    one()
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or time.perf_counter() - t0 < 10.0:
+        one()
+        reps += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(B / dt, 2), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} steps of batch {B} (same shapes; fp32; oracle = reference op sequence, "
+                      f"per-sample grads by vmap)"}
+
+
+def main():
+    args = parse()
+    from vqa_amd import dist as vdist
+    from vqa_amd import ops
+    rank, local, world = vdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    lo, hi = vdist.shard_range(args.batch, rank, world)
+    local_b = hi - lo
+
+    fus, gsm, opt, main_opt, sets = build_job(dev, local_b, dtype, rank)
+    step = make_step(fus, gsm, opt, main_opt, sets)
+    probe = Probe("gather_mix_pool:0")
+    ops.PROBE = probe
+
+    for i in range(args.warmup):
+        step(i)
+    vdist.barrier()
+    torch.cuda.synchronize()
+    probe.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    vdist.barrier()
+    dt = time.perf_counter() - t0
+    probe.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        s = 2 if dtype == torch.bfloat16 else 4
+        K = ops.keep_count(N_VIS, 1 - KEEP)
+        # algorithmic bytes of the pooled prune+mix launch on the vision tokens: every token row
+        # read once, the keep indices read, one pooled row written
+        alg_bytes = local_b * (N_VIS * D * s + K * 8 + D * s)
+        k_ms = probe.mean_ms()
+        achieved = alg_bytes / k_ms / 1e6 if k_ms > 0 else 0.0
+        line = {
+            "metric": "DP-SGD train samples/s (fusion+classifier+DP step, token-level inputs)",
+            "value": round(args.batch * args.steps / dt, 1),
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: DP-SGD step, C=1.0, sigma=1.0, logical batch "
+                                   f"{args.batch} sharded over {world} GPU(s); CoAttention pruning keep 0.5, "
+                                   f"{N_VIS} vision + {N_TXT} text tokens x {D}, {C} classes; encoders bypassed",
+                       "global_batch": args.batch, "per_gpu_batch": local_b, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": "gather_mix_kernel<pool> (vision tokens)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_ms": round(k_ms, 5), "algorithmic_bytes": alg_bytes},
+        }
+        if not args.no_sweep:
+            line["prune_mix_cfg4"] = prune_mix_sweep(dev, dtype)
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,259 @@
+"""GPU parity of the DP-SGD step kernels against the per-sample-gradient oracle
+(oracle/dp_oracle.py; parity unpinned by the reference, see its header), and of the MIA scoring
+kernel against the golden vectors captured from the reference model.
+
+Tolerances: f32 rtol 1e-5 on per-sample norms, clip factors and clipped sums (atol scaled to the
+magnitude of the sums); bf16 rtol 1e-2.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import load_golden
+from oracle import dp_oracle as do
+from oracle import fusion_oracle as fo
+from oracle import inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from vqa_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _classifier(seed, in_dim, hidden, C):
+    m = do.make_classifier(in_dim, hidden, C, dp_fixed=True)
+    m.load_state_dict(gi.classifier_params(seed, in_dim, hidden, C))
+    return m.eval()  # dropout off: the oracle's vmap cannot replay a dropout stream
+
+
+def _flat_to_named(opt, module, flat):
+    out = {}
+    names = {id(p): n for n, p in module.named_parameters()}
+    for p in opt.params:
+        o = opt._offsets[id(p)]
+        out[names[id(p)]] = flat[o:o + p.numel()].view_as(p).cpu()
+    return out
+
+
+@pytest.mark.parametrize("in_dim,hidden,C,B,max_norm", [
+    (1024, 1024, 430, 6, 1.0),     # BASELINE classifier, every sample clipped
+    (1024, 1024, 430, 5, 1e4),     # nothing clipped
+    (64, 64, 13, 33, 1.0),         # small groups (gs = 4), ragged tile edges
+    (128, 256, 100, 70, 0.5),
+])
+def test_dp_step_f32_vs_oracle(dev, in_dim, hidden, C, B, max_norm):
+    from vqa_amd import dp
+    cpu_m = _classifier(100 + hidden, in_dim, hidden, C)
+    x = gi.normal(7 + B, B, in_dim)
+    y = gi.labels(8 + B, B, C)
+    sigma, E = 1.0, 64
+    # the same standard-normal draw on both sides, laid out parameter by parameter
+    z = {n: gi.normal(1000 + i, *p.shape) for i, (n, p) in enumerate(cpu_m.named_parameters())}
+    norms, clip, sums, grads = do.dp_step(cpu_m, x, y, max_norm, sigma, E, noise=z)
+
+    gpu_m = _classifier(100 + hidden, in_dim, hidden, C).to(dev)
+    gsm = dp.GradSampleModule(gpu_m)
+    inner = torch.optim.SGD(gpu_m.parameters(), lr=0.1)
+    opt = dp.DPOptimizer(inner, gsm, noise_multiplier=sigma, max_grad_norm=max_norm, expected_batch_size=E)
+    xg = x.to(dev).requires_grad_()
+    logits = gsm(xg)
+    loss = nn.CrossEntropyLoss()(logits, y.to(dev))
+    loss.backward()
+    assert all(p.grad is None for p in gpu_m.parameters())  # no unclipped gradient is ever formed
+    S = opt.clip_and_accumulate().clone()
+    # groups of 2-4 channels make xhat ill-conditioned (variance of two numbers): 1e-4 there
+    rtol_n = 1e-5 if hidden >= 256 else 1e-4
+    np.testing.assert_allclose(opt.last_norms.cpu().numpy(), norms.numpy(), rtol=rtol_n)
+    np.testing.assert_allclose(opt.last_clip.cpu().numpy(), clip.numpy(), rtol=rtol_n)
+    got = _flat_to_named(opt, gsm, S)
+    for n, want in sums.items():
+        scale = max(1e-6, float(want.abs().max()))
+        np.testing.assert_allclose(got["_module." + n].numpy(), want.numpy(), rtol=rtol_n, atol=20 * rtol_n * scale / 100,
+                                   err_msg=n)
+    # noise + scale with the injected draw
+    flat_z = torch.zeros(opt._numel)
+    for (o, numel, shape), (n, p) in zip(opt.flat_noise_layout(), cpu_m.named_parameters()):
+        flat_z[o:o + numel] = z[n].reshape(-1)
+    opt.add_noise_and_scale(noise=flat_z.to(dev))
+    for n, p in gsm.named_parameters():
+        want = grads[n.replace("_module.", "")]
+        scale = max(1e-6, float(want.abs().max()))
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want.numpy(), rtol=rtol_n, atol=20 * rtol_n * scale / 100, err_msg=n)
+    # input gradient (flows on to the non-private fusion / encoders): plain autograd value
+    cx = x.clone().requires_grad_()
+    nn.CrossEntropyLoss()(cpu_m(cx), y).backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), cx.grad.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), cpu_m(x).detach().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_dp_kernels_bf16_same_inputs(dev):
+    """bf16 storage, kernel by kernel on identical bf16 operands: ghost norms, clipped sums and
+    GroupNorm against f32 math on the same rounded values (rtol 1e-2 is the stated bar; the f32
+    accumulation actually lands far inside it)."""
+    from vqa_amd._lib import BF16, check, load, ptr, stream_ptr
+    lib, st = load(), stream_ptr(dev)
+    B, In, Out = 37, 1024, 430
+    a = gi.normal(1, B, In).bfloat16()
+    g = (gi.normal(2, B, Out) * 1e-2).bfloat16()
+    coef = torch.rand(B) + 0.5
+    ad, gd, cd = a.to(dev), g.to(dev), coef.to(dev)
+    sq = torch.empty(B, device=dev)
+    check(lib.vqaf_ghost_sqnorm_linear(ptr(ad), ptr(gd), B, In, Out, BF16, 1, 0, ptr(sq), st), "sq")
+    af, gf = a.double(), g.double()
+    want = af.pow(2).sum(1) * gf.pow(2).sum(1) + gf.pow(2).sum(1)
+    np.testing.assert_allclose(sq.cpu().numpy(), want.numpy(), rtol=1e-5)
+    SW = torch.empty(Out, In, device=dev)
+    Sb = torch.empty(Out, device=dev)
+    check(lib.vqaf_clipped_sum_linear(ptr(ad), ptr(gd), ptr(cd), B, In, Out, BF16, 0, ptr(SW), ptr(Sb), st), "cs")
+    wantW = torch.einsum("b,bo,bi->oi", coef.double(), gf, af)
+    np.testing.assert_allclose(SW.cpu().numpy(), wantW.numpy(), rtol=1e-2, atol=1e-6)
+    np.testing.assert_allclose(Sb.cpu().numpy(), (coef.double()[:, None] * gf).sum(0).numpy(), rtol=1e-2, atol=1e-6)
+    # accumulate flag adds a second micro-batch
+    check(lib.vqaf_clipped_sum_linear(ptr(ad), ptr(gd), ptr(cd), B, In, Out, BF16, 1, ptr(SW), ptr(Sb), st), "cs")
+    np.testing.assert_allclose(SW.cpu().numpy(), 2 * wantW.numpy(), rtol=1e-2, atol=1e-6)
+    # GroupNorm + ReLU forward / backward in bf16 storage
+    C, groups = 2048, 32
+    x = gi.normal(3, B, C).bfloat16()
+    gam, bet = (1 + 0.1 * gi.normal(4, C)).bfloat16(), (0.1 * gi.normal(5, C)).bfloat16()
+    y = torch.empty(B, C, dtype=torch.bfloat16, device=dev)
+    xh = torch.empty_like(y)
+    rstd = torch.empty(B, groups, device=dev)
+    xd, gamd, betd = x.to(dev), gam.to(dev), bet.to(dev)  # keep the device copies alive
+    check(lib.vqaf_groupnorm_fwd(ptr(xd), ptr(gamd), ptr(betd), B, C, groups, 1e-5, 1,
+                                 BF16, ptr(y), ptr(xh), ptr(rstd), st), "gn")
+    want_y = torch.relu(torch.nn.functional.group_norm(x.float(), groups, gam.float(), bet.float(), 1e-5))
+    np.testing.assert_allclose(y.float().cpu().numpy(), want_y.numpy(), rtol=1e-2, atol=1e-2)
+
+
+def test_dp_step_bf16_end_to_end(dev):
+    """Whole classifier in bf16 storage against the f32 oracle.  bf16 rounding of the
+    pre-activations flips a few ReLU gates, so element-wise bars do not apply; direction and
+    size of every clipped sum must still agree."""
+    from vqa_amd import dp
+    in_dim, hidden, C, B = 1024, 1024, 430, 8
+    cpu_m = _classifier(300, in_dim, hidden, C)
+    x = gi.normal(9, B, in_dim).bfloat16().float()
+    y = gi.labels(10, B, C)
+    norms, clip, sums, _ = do.dp_step(cpu_m, x, y, 1.0, 0.0, B)
+    gpu_m = _classifier(300, in_dim, hidden, C).to(dev)
+    gsm = dp.GradSampleModule(gpu_m)
+    opt = dp.DPOptimizer(torch.optim.SGD(gpu_m.parameters(), lr=0.1), gsm, noise_multiplier=0.0,
+                         max_grad_norm=1.0, expected_batch_size=B)
+    logits = gsm(x.to(dev).bfloat16())
+    assert logits.dtype == torch.bfloat16
+    np.testing.assert_allclose(logits.detach().float().cpu().numpy(), cpu_m(x).detach().numpy(), rtol=1e-2, atol=3e-2)
+    nn.CrossEntropyLoss()(logits.float(), y.to(dev)).backward()
+    S = opt.clip_and_accumulate()
+    np.testing.assert_allclose(opt.last_norms.cpu().numpy(), norms.numpy(), rtol=2e-2)
+    got = _flat_to_named(opt, gsm, S)
+    for n, want in sums.items():
+        g = got["_module." + n].double().reshape(-1)
+        w = want.double().reshape(-1)
+        cos = float((g @ w) / (g.norm() * w.norm()))
+        assert cos > 0.99 and abs(float(g.norm() / w.norm()) - 1) < 3e-2, (n, cos)
+
+
+def test_noise_scale_in_kernel_draws(dev):
+    """The in-kernel Gaussian: statistics, reproducibility from (seed, counter), and independence
+    of the launch geometry (element i always uses the same draw)."""
+    from vqa_amd import ops
+    from vqa_amd._lib import check, load, ptr, stream_ptr
+    n = 4_644_270  # parameter count of the BASELINE classifier
+    S = torch.zeros(n, device=dev)
+    out = torch.empty(n, device=dev)
+    rng = ops.PhiloxState(dev, seed=99)
+    check(load().vqaf_noise_scale(ptr(S), None, ptr(rng.state), 2.0, 0.5, n, ptr(out), stream_ptr(dev)), "ns")
+    z = out.cpu().double()  # = N(0,1) since 2.0 * 0.5 = 1
+    assert abs(z.mean().item()) < 5 / n ** 0.5
+    assert abs(z.std().item() - 1.0) < 3e-3
+    assert abs((z ** 4).mean().item() - 3.0) < 2e-2
+    assert 4.5 < z.abs().max().item() < 7.0
+    # a shorter call sees the same leading draws
+    m = 1001
+    out2 = torch.empty(m, device=dev)
+    check(load().vqaf_noise_scale(ptr(S), None, ptr(rng.state), 2.0, 0.5, m, ptr(out2), stream_ptr(dev)), "ns")
+    assert torch.equal(out2.cpu(), out[:m].cpu())
+    rng.advance()
+    check(load().vqaf_noise_scale(ptr(S), None, ptr(rng.state), 2.0, 0.5, m, ptr(out2), stream_ptr(dev)), "ns")
+    assert not torch.equal(out2.cpu(), out[:m].cpu())
+    # std 0 -> pure scaling
+    S.fill_(3.0)
+    check(load().vqaf_noise_scale(ptr(S), None, None, 0.0, 0.25, n, ptr(out), stream_ptr(dev)), "ns")
+    assert torch.equal(out.cpu(), torch.full((n,), 0.75))
+
+
+def test_privacy_engine_surface_and_training_step(dev):
+    """The call sequence of train.py:124-164 + utils/src.py:66-106 on a tiny problem."""
+    from vqa_amd import dp
+    torch.manual_seed(0)
+    cls = nn.Sequential(nn.Linear(64, 128), nn.BatchNorm1d(128), nn.ReLU(), nn.Dropout(0.3),
+                        nn.Linear(128, 64), nn.BatchNorm1d(64), nn.ReLU(), nn.Linear(64, 13))
+    cls = dp.ModuleValidator.fix(cls).to(dev)
+    assert isinstance(cls[1], nn.GroupNorm) and cls[1].num_groups == 32 and isinstance(cls[5], nn.GroupNorm)
+    ds = torch.utils.data.TensorDataset(torch.randn(256, 64), torch.randint(0, 13, (256,)))
+    loader = torch.utils.data.DataLoader(ds, batch_size=32, shuffle=True)
+    engine = dp.PrivacyEngine(secure_mode=False)
+    opt = torch.optim.AdamW(cls.parameters(), lr=1e-2, weight_decay=0.01)
+    module, opt, loader = engine.make_private(module=cls, optimizer=opt, data_loader=loader,
+                                              noise_multiplier=1.0, max_grad_norm=1.0, poisson_sampling=True)
+    assert sorted(module.state_dict())[0].startswith("_module.")
+    assert opt.expected_batch_size == 32
+    before = [p.detach().clone() for p in module.parameters()]
+    steps = 0
+    module.train()
+    for batch in loader:
+        if batch is None:
+            continue
+        xb, yb = batch
+        opt.zero_grad()
+        loss = nn.CrossEntropyLoss()(module(xb.to(dev)), yb.to(dev))
+        loss.backward()
+        opt.step()
+        steps += 1
+        assert bool((opt.last_norms * opt.last_clip <= 1.0 + 1e-4).all())  # every sample clipped to C
+    assert steps >= 6
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, module.parameters()))
+    eps = engine.get_epsilon(1e-5)
+    assert 0.1 < eps < 50
+    engine2 = dp.PrivacyEngine()
+    cls2 = dp.ModuleValidator.fix(nn.Sequential(nn.Linear(64, 64), nn.BatchNorm1d(64), nn.ReLU(),
+                                                nn.Linear(64, 13))).to(dev)
+    _, opt2, _ = engine2.make_private_with_epsilon(
+        module=cls2, optimizer=torch.optim.AdamW(cls2.parameters()), target_epsilon=3.0, target_delta=1e-5,
+        data_loader=torch.utils.data.DataLoader(ds, batch_size=32), epochs=5, max_grad_norm=10.0)
+    assert 0.3 < opt2.noise_multiplier < 5.0
+
+
+# ------------------------------------------------------------------ MIA scoring
+def test_ce_conf_vs_golden(dev):
+    from vqa_amd import mia
+    g = load_golden("model_N197")
+    logits, y = torch.from_numpy(g["logits"]).to(dev), torch.from_numpy(g["targets"]).to(dev)
+    loss, conf, pred = mia.score_logits(logits, y)
+    np.testing.assert_allclose(loss.cpu().numpy(), g["loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(conf.cpu().numpy(), g["conf"], rtol=1e-5, atol=1e-7)
+    assert np.array_equal(pred.cpu().numpy(), g["pred"])
+
+
+def test_ce_conf_shapes_dtypes_and_gradient(dev):
+    from vqa_amd import ops
+    for B, C in ((1, 1), (7, 13), (130, 430), (33, 1000)):
+        lg = gi.normal(B + C, B, C, scale=3.0)
+        y = gi.labels(B, B, C)
+        loss, conf, pred, grad = ops.ce_conf(lg.to(dev), y.to(dev), want_pred=True, grad_scale=1.0 / B)
+        np.testing.assert_allclose(loss.cpu().numpy(), fo.per_sample_ce(lg, y).numpy(), rtol=1e-5, atol=1e-6)
+        c_ref, p_ref = fo.max_softmax(lg)
+        np.testing.assert_allclose(conf.cpu().numpy(), c_ref.numpy(), rtol=1e-5, atol=1e-7)
+        assert torch.equal(pred.cpu(), p_ref)
+        lr = lg.clone().requires_grad_()
+        nn.CrossEntropyLoss()(lr, y).backward()
+        np.testing.assert_allclose(grad.cpu().numpy(), lr.grad.numpy(), rtol=1e-5, atol=1e-8)
+        lb = lg.bfloat16()
+        loss_b, conf_b, _, _ = ops.ce_conf(lb.to(dev), y.to(dev))
+        np.testing.assert_allclose(loss_b.cpu().numpy(), fo.per_sample_ce(lb.float(), y).numpy(), rtol=1e-5, atol=1e-6)

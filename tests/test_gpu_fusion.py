@@ -261,8 +261,11 @@ def test_adversarial_swap_random_properties(dev):
         assert 0 <= int(pos[b].min()) and int(pos[b].max()) < K
         assert 0 <= int(src[b].min()) and int(src[b].max()) < N - K
         assert len(set(top_c[b].tolist())) == K  # still duplicate-free
-    # what the kernel did == the reference's loop body replayed with the recorded draws
-    want, _ = fo.select_indices(w.cpu(), N, 0.5, True, 0.2, pos, src)
+    # what the kernel did == the reference's loop body (utils/fusion.py:65) replayed with the
+    # recorded draws on the same top/bottom lists
+    want = top0_c.clone()
+    for b in range(B):
+        want[b, pos[b]] = bottom_c[b][src[b]]
     assert torch.equal(top_c, want)
     # same state -> same draws; advanced state -> different draws
     rng2 = ops.PhiloxState(dev, seed=1234)

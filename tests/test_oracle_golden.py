@@ -11,7 +11,12 @@ from conftest import GOLDEN, load_golden
 from oracle import fusion_oracle as fo
 from oracle import inputs as gi
 
-torch.set_grad_enabled(False)
+
+
+@pytest.fixture(autouse=True)
+def _no_grad():
+    with torch.no_grad():
+        yield
 
 
 def _names(prefix):

@@ -210,35 +210,68 @@ groupnorm_fwd_kernel(const void* __restrict__ x, const void* __restrict__ gamma,
                      const void* __restrict__ beta, int C, int groups, float eps, int relu,
                      void* __restrict__ y, void* __restrict__ xhat, float* __restrict__ rstd) {
   const int b = blockIdx.x;
-  const int gs = C / groups, lpg = gs / 8;
+  const int gs = C / groups, lpg = gs >= 8 ? gs / 8 : 1;
   for (int c0 = threadIdx.x * 8; c0 < C; c0 += DP_THREADS * 8) {
-    float v[8];
+    float v[8], rsv[8];
     load8<BF16>(x, (size_t)b * C + c0, v);
-    float s = 0.f;
+    if (gs >= 8) {
+      float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += v[i];
-    for (int o = lpg >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s / (float)gs;
-    float q = 0.f;
+      for (int i = 0; i < 8; ++i) s += v[i];
+      for (int o = lpg >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s / (float)gs;
+      float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      v[i] -= mean;
-      q = fmaf(v[i], v[i], q);
+      for (int i = 0; i < 8; ++i) {
+        v[i] -= mean;
+        q = fmaf(v[i], v[i], q);
+      }
+      for (int o = lpg >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      const float rs = rsqrtf(q / (float)gs + eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rsv[i] = rs;
+      if ((threadIdx.x % lpg) == 0) rstd[(size_t)b * groups + c0 / gs] = rs;
+    } else {
+      // several groups inside one lane's 8 channels (gs in {1,2,4}): segmented butterflies
+      float s[8], q[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = v[i];
+      for (int o = 1; o < gs; o <<= 1) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = s[i ^ o];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] += t[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] -= s[i] / (float)gs;
+        q[i] = v[i] * v[i];
+      }
+      for (int o = 1; o < gs; o <<= 1) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = q[i ^ o];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] += t[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        rsv[i] = rsqrtf(q[i] / (float)gs + eps);
+        if ((i % gs) == 0) rstd[(size_t)b * groups + (c0 + i) / gs] = rsv[i];
+      }
     }
-    for (int o = lpg >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-    const float rs = rsqrtf(q / (float)gs + eps);
     float ga[8], be[8], yo[8];
     load8<BF16>(gamma, (size_t)c0, ga);
     load8<BF16>(beta, (size_t)c0, be);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      v[i] *= rs;
+      v[i] *= rsv[i];
       yo[i] = fmaf(v[i], ga[i], be[i]);
       if (relu) yo[i] = fmaxf(yo[i], 0.f);
     }
     store8<BF16>(y, (size_t)b * C + c0, yo);
     store8<BF16>(xhat, (size_t)b * C + c0, v);
-    if (rstd != nullptr && ((threadIdx.x % lpg) == 0)) rstd[(size_t)b * groups + c0 / gs] = rs;
   }
 }
 
@@ -249,7 +282,7 @@ groupnorm_bwd_kernel(const void* __restrict__ grad_y, const void* __restrict__ y
                      const void* __restrict__ gamma, int C, int groups, int relu,
                      void* __restrict__ g_pre, void* __restrict__ grad_x) {
   const int b = blockIdx.x;
-  const int gs = C / groups, lpg = gs / 8;
+  const int gs = C / groups, lpg = gs >= 8 ? gs / 8 : 1;
   for (int c0 = threadIdx.x * 8; c0 < C; c0 += DP_THREADS * 8) {
     float gy[8], xh[8], ga[8], yo[8];
     load8<BF16>(grad_y, (size_t)b * C + c0, gy);
@@ -261,21 +294,44 @@ groupnorm_bwd_kernel(const void* __restrict__ grad_y, const void* __restrict__ y
       for (int i = 0; i < 8; ++i) gy[i] = yo[i] > 0.f ? gy[i] : 0.f;
     }
     store8<BF16>(g_pre, (size_t)b * C + c0, gy);
-    float s1 = 0.f, s2 = 0.f, dx[8];
+    float dx[8];
+    if (gs >= 8) {
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      dx[i] = gy[i] * ga[i];
-      s1 += dx[i];
-      s2 = fmaf(dx[i], xh[i], s2);
-    }
-    for (int o = lpg >> 1; o > 0; o >>= 1) {
-      s1 += __shfl_xor(s1, o, 64);
-      s2 += __shfl_xor(s2, o, 64);
-    }
-    const float rs = rstd[(size_t)b * groups + c0 / gs];
-    const float m1 = s1 / (float)gs, m2 = s2 / (float)gs;
+      for (int i = 0; i < 8; ++i) {
+        dx[i] = gy[i] * ga[i];
+        s1 += dx[i];
+        s2 = fmaf(dx[i], xh[i], s2);
+      }
+      for (int o = lpg >> 1; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+      }
+      const float rs = rstd[(size_t)b * groups + c0 / gs];
+      const float m1 = s1 / (float)gs, m2 = s2 / (float)gs;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dx[i] = rs * (dx[i] - m1 - xh[i] * m2);
+      for (int i = 0; i < 8; ++i) dx[i] = rs * (dx[i] - m1 - xh[i] * m2);
+    } else {
+      float s1[8], s2[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        dx[i] = gy[i] * ga[i];
+        s1[i] = dx[i];
+        s2[i] = dx[i] * xh[i];
+      }
+      for (int o = 1; o < gs; o <<= 1) {
+        float t1[8], t2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { t1[i] = s1[i ^ o]; t2[i] = s2[i ^ o]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1[i] += t1[i]; s2[i] += t2[i]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float rs = rstd[(size_t)b * groups + (c0 + i) / gs];
+        dx[i] = rs * (dx[i] - s1[i] / (float)gs - xh[i] * (s2[i] / (float)gs));
+      }
+    }
     store8<BF16>(grad_x, (size_t)b * C + c0, dx);
   }
 }
@@ -322,6 +378,8 @@ ce_conf_kernel(const void* __restrict__ logits, const int64_t* __restrict__ targ
 bool gn_shape_ok(int C, int groups) {
   if (groups <= 0 || C % groups != 0) return false;
   const int gs = C / groups;
+  if (C % 8 != 0) return false;
+  if (gs < 8) return gs == 1 || gs == 2 || gs == 4;
   if (gs % 8 != 0) return false;
   const int lpg = gs / 8;
   return lpg <= 64 && (lpg & (lpg - 1)) == 0;

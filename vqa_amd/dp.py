@@ -1,0 +1,458 @@
+"""DP-SGD engine for the classifier, shaped like the Opacus surface the reference uses.
+
+The reference delegates DP-SGD to Opacus 1.4.0 (train.py:12-13, 124-153; utils/src.py:99,104):
+
+    model.classifier = ModuleValidator.fix(model.classifier)
+    privacy_engine = PrivacyEngine(secure_mode=False)
+    module, optimizer, loader = privacy_engine.make_private(module=, optimizer=, data_loader=,
+                                    noise_multiplier=, max_grad_norm=, poisson_sampling=True)
+    ... loss.backward(); optimizer.step(); privacy_engine.get_epsilon(delta)
+
+The classes below keep those names and call shapes.  What differs is how the work is done:
+per-sample gradients are never materialised (Opacus stores a (B, out, in) tensor per Linear).
+Each wrapped layer records its input a_i and its output gradient g_i; the optimizer step then
+runs, on the HIP kernels of libvqafuse,
+
+    ghost norms    n_i^2 = sum_layers ||a_i||^2 ||g_i||^2 (+ bias / affine terms)
+    clip           c_i  = min(1, C / (n_i + 1e-6))
+    clipped sums   S    = sum_i c_i g_i a_i^T            (batch-contraction GEMM on MFMA)
+    noise + scale  grad = (S + N(0, (sigma C)^2)) / expected_batch_size
+
+and hands `grad` to the wrapped torch optimizer.  With torch.distributed initialised the
+clipped sums are all-reduced (RCCL) in one flat bucket and each rank adds an independent
+N(0, (sigma C)^2 / world) share from its own rank-seeded stream, so the total noise is added
+exactly once.
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import check, dtype_code, load, ptr, stream_ptr
+from .accountant import RDPAccountant, get_noise_multiplier
+
+
+# --------------------------------------------------------------------------------------------
+# ModuleValidator.fix  (train.py:124)
+# --------------------------------------------------------------------------------------------
+class ModuleValidator:
+    """BatchNorm mixes samples, which per-sample clipping cannot allow; `fix` swaps every
+    BatchNorm1d(n) for GroupNorm(min(32, n), n, affine) as Opacus' fixer does (fresh affine
+    parameters), in place for containers, and returns the module."""
+
+    SUPPORTED = (nn.Linear, nn.GroupNorm)
+
+    @staticmethod
+    def fix(module: nn.Module) -> nn.Module:
+        if isinstance(module, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+            return ModuleValidator._to_groupnorm(module)
+        for name, child in list(module.named_children()):
+            setattr(module, name, ModuleValidator.fix(child))
+        return module
+
+    @staticmethod
+    def _to_groupnorm(bn: nn.Module) -> nn.GroupNorm:
+        gn = nn.GroupNorm(min(32, bn.num_features), bn.num_features, affine=bn.affine)
+        ref = next(bn.parameters(), None)
+        if ref is not None:
+            gn = gn.to(device=ref.device, dtype=ref.dtype)
+        return gn
+
+    @staticmethod
+    def validate(module: nn.Module, strict: bool = False) -> List[str]:
+        errors = []
+        for name, m in module.named_modules():
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+                errors.append(f"{name}: BatchNorm is not DP-compatible (use ModuleValidator.fix)")
+            elif next(m.parameters(recurse=False), None) is not None and \
+                    not isinstance(m, ModuleValidator.SUPPORTED):
+                errors.append(f"{name}: {type(m).__name__} has parameters but no per-sample rule")
+        if strict and errors:
+            raise ValueError("; ".join(errors))
+        return errors
+
+    @staticmethod
+    def is_valid(module: nn.Module) -> bool:
+        return not ModuleValidator.validate(module)
+
+
+# --------------------------------------------------------------------------------------------
+# Layer wrappers that record (a_i, g_i) instead of computing parameter gradients
+# --------------------------------------------------------------------------------------------
+class _Tape:
+    """What one wrapped layer leaves behind for the optimizer step."""
+
+    __slots__ = ("module", "kind", "a", "g")
+
+    def __init__(self, module: nn.Module, kind: str):
+        self.module, self.kind, self.a, self.g = module, kind, None, None
+
+
+class _GhostLinear(torch.autograd.Function):
+    """y = x W^T + b through the vendor GEMM; backward returns only dL/dx and records dL/dy.
+    The weight gradient is NOT computed here -- the clipped sum replaces it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, tape):
+        w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+        b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
+        y = F.linear(x, w, b)
+        ctx.save_for_backward(w)
+        ctx.tape = tape
+        tape.a = x.detach()
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (w,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        ctx.tape.g = gy
+        gx = gy.matmul(w) if ctx.needs_input_grad[0] else None
+        return gx, None, None, None
+
+
+class _GhostGroupNorm(torch.autograd.Function):
+    """GroupNorm (+ fused ReLU) on (B,C) by vqaf_groupnorm_fwd/bwd; records xhat and the
+    gradient at the affine output."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, relu, tape):
+        B, C = x.shape
+        xc = x.contiguous()
+        ga = weight.detach().to(x.dtype).contiguous()
+        be = bias.detach().to(x.dtype).contiguous()
+        y = torch.empty_like(xc)
+        xhat = torch.empty_like(xc)
+        rstd = torch.empty(B, groups, dtype=torch.float32, device=x.device)
+        check(load().vqaf_groupnorm_fwd(ptr(xc), ptr(ga), ptr(be), B, C, groups, float(eps), int(relu),
+                                        dtype_code(xc), ptr(y), ptr(xhat), ptr(rstd),
+                                        stream_ptr(x.device)), "vqaf_groupnorm_fwd")
+        ctx.save_for_backward(y, xhat, rstd, ga)
+        ctx.meta = (B, C, groups, int(relu))
+        ctx.tape = tape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, xhat, rstd, ga = ctx.saved_tensors
+        B, C, groups, relu = ctx.meta
+        gy = gy.contiguous().to(y.dtype)
+        g_pre = torch.empty_like(y)
+        gx = torch.empty_like(y)
+        check(load().vqaf_groupnorm_bwd(ptr(gy), ptr(y), ptr(xhat), ptr(rstd), ptr(ga), B, C, groups,
+                                        relu, dtype_code(y), ptr(g_pre), ptr(gx),
+                                        stream_ptr(y.device)), "vqaf_groupnorm_bwd")
+        ctx.tape.a = xhat
+        ctx.tape.g = g_pre
+        return gx, None, None, None, None, None, None
+
+
+class GradSampleModule(nn.Module):
+    """Wraps the classifier; the wrapped module is `_module`, so state_dict keys gain the
+    `_module.` prefix the reference's loader strips (utils/util.py:117-123)."""
+
+    def __init__(self, m: nn.Module, *, batch_first: bool = True, loss_reduction: str = "mean"):
+        super().__init__()
+        errors = ModuleValidator.validate(m)
+        if errors:
+            raise ValueError("module is not DP-compatible: " + "; ".join(errors))
+        if loss_reduction not in ("mean", "sum"):
+            raise ValueError("loss_reduction must be 'mean' or 'sum'")
+        self._module = m
+        self.loss_reduction = loss_reduction
+        self.tapes: List[_Tape] = []
+        self.last_batch_size = 0
+
+    def forward(self, x):
+        self.tapes = []
+        self.last_batch_size = x.shape[0]
+        return self._run(self._module, x)
+
+    def _run(self, m: nn.Module, x):
+        if isinstance(m, nn.Sequential):
+            children = list(m.children())
+            i = 0
+            while i < len(children):
+                c = children[i]
+                if isinstance(c, nn.GroupNorm) and i + 1 < len(children) and \
+                        isinstance(children[i + 1], nn.ReLU) and x.dim() == 2:
+                    x = self._groupnorm(c, x, relu=True)
+                    i += 2
+                    continue
+                x = self._run(c, x)
+                i += 1
+            return x
+        if isinstance(m, nn.Linear):
+            if x.dim() != 2:
+                raise ValueError("per-sample rule implemented for Linear on (B, features) input")
+            tape = _Tape(m, "linear")
+            self.tapes.append(tape)
+            return _GhostLinear.apply(x, m.weight, m.bias, tape)
+        if isinstance(m, nn.GroupNorm):
+            return self._groupnorm(m, x, relu=False)
+        if next(m.parameters(), None) is None:
+            return m(x)  # ReLU, Dropout, Identity ...: parameter-free, plain autograd
+        raise ValueError(f"{type(m).__name__} has parameters but no per-sample rule")
+
+    def _groupnorm(self, m: nn.GroupNorm, x, relu: bool):
+        if x.dim() != 2 or not m.affine:
+            raise ValueError("per-sample rule implemented for affine GroupNorm on (B, C) input")
+        tape = _Tape(m, "affine")
+        self.tapes.append(tape)
+        return _GhostGroupNorm.apply(x, m.weight, m.bias, m.num_groups, m.eps, relu, tape)
+
+
+# --------------------------------------------------------------------------------------------
+# DPOptimizer
+# --------------------------------------------------------------------------------------------
+class DPOptimizer:
+    """clip -> sum -> (all-reduce) -> noise -> scale -> wrapped optimizer step."""
+
+    def __init__(self, optimizer: torch.optim.Optimizer, module: GradSampleModule, *,
+                 noise_multiplier: float, max_grad_norm: float, expected_batch_size: int,
+                 seed: Optional[int] = None, process_group=None):
+        self.original_optimizer = optimizer
+        self.module = module
+        self.noise_multiplier = float(noise_multiplier)
+        self.max_grad_norm = float(max_grad_norm)
+        self.expected_batch_size = int(expected_batch_size)
+        self.process_group = process_group
+        self.accountant_hook = None
+        self.params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
+        self._offsets = {}
+        off = 0
+        for p in self.params:
+            self._offsets[id(p)] = off
+            off += (p.numel() + 3) // 4 * 4  # keep every slice 16-byte aligned
+        self._numel = off
+        self._S = None
+        self._grad = None
+        self._rng = None
+        self._seed = seed
+        self.last_norms = None
+        self.last_clip = None
+
+    # -- torch.optim.Optimizer surface the training loop touches ------------------------------
+    @property
+    def param_groups(self):
+        return self.original_optimizer.param_groups
+
+    def state_dict(self):
+        return self.original_optimizer.state_dict()
+
+    def load_state_dict(self, sd):
+        self.original_optimizer.load_state_dict(sd)
+
+    def zero_grad(self, set_to_none: bool = False):
+        # Parameter .grad tensors are views of the flat buffer and are overwritten by every
+        # step; the only per-step state is the recorded backprops.
+        for t in self.module.tapes:
+            t.g = None
+
+    def attach_step_hook(self, fn):
+        self.accountant_hook = fn
+
+    # -- the DP step ---------------------------------------------------------------------------
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+        return 1, 0
+
+    def _buffers(self, device):
+        if self._S is None or self._S.device != device:
+            self._S = torch.zeros(self._numel, dtype=torch.float32, device=device)
+            self._grad = torch.zeros(self._numel, dtype=torch.float32, device=device)
+            for p in self.params:
+                o = self._offsets[id(p)]
+                p.grad = self._grad[o:o + p.numel()].view_as(p)
+            world, rank = self._world()
+            seed = self._seed if self._seed is not None else torch.initial_seed()
+            self._rng = ops.PhiloxState(device, seed=seed, stream_salt=1 + rank)
+        return self._S, self._grad
+
+    def _slice(self, buf, p):
+        o = self._offsets[id(p)]
+        return buf[o:o + p.numel()]
+
+    @torch.no_grad()
+    def clip_and_accumulate(self):
+        """Fills the flat clipped-sum buffer from the layer tapes; returns it."""
+        tapes = [t for t in self.module.tapes if t.g is not None]
+        if not tapes:
+            raise RuntimeError("DPOptimizer.step() called before loss.backward()")
+        lib = load()
+        dev = tapes[0].g.device
+        S, _ = self._buffers(dev)
+        B = tapes[0].g.shape[0]
+        st = stream_ptr(dev)
+        sq = torch.empty(B, dtype=torch.float32, device=dev)
+        for i, t in enumerate(tapes):
+            a, g = t.a.contiguous(), t.g.contiguous()
+            if a.dtype != g.dtype:
+                a = a.to(g.dtype)
+                t.a = a
+            if t.kind == "linear":
+                check(lib.vqaf_ghost_sqnorm_linear(ptr(a), ptr(g), B, a.shape[1], g.shape[1],
+                                                   dtype_code(g), int(t.module.bias is not None),
+                                                   int(i > 0), ptr(sq), st), "vqaf_ghost_sqnorm_linear")
+            else:
+                check(lib.vqaf_ghost_sqnorm_affine(ptr(a), ptr(g), B, g.shape[1], dtype_code(g),
+                                                   int(i > 0), ptr(sq), st), "vqaf_ghost_sqnorm_affine")
+        # a mean-reduced loss hands back gradients divided by B; undo it (Opacus: loss_reduction)
+        scale = float(B) if self.module.loss_reduction == "mean" else 1.0
+        coef = torch.empty(B, dtype=torch.float32, device=dev)
+        norms = torch.empty(B, dtype=torch.float32, device=dev)
+        check(lib.vqaf_clip_coef(ptr(sq), B, self.max_grad_norm, scale, ptr(coef), ptr(norms), st),
+              "vqaf_clip_coef")
+        self.last_norms, self.last_clip = norms, coef / scale
+        for t in tapes:
+            a, g = t.a, t.g.contiguous()
+            m = t.module
+            if t.kind == "linear":
+                sw = self._slice(S, m.weight)
+                sb = self._slice(S, m.bias) if m.bias is not None else None
+                check(lib.vqaf_clipped_sum_linear(ptr(a), ptr(g), ptr(coef), B, a.shape[1], g.shape[1],
+                                                  dtype_code(g), 0, ptr(sw), ptr(sb), st),
+                      "vqaf_clipped_sum_linear")
+            else:
+                check(lib.vqaf_clipped_sum_affine(ptr(a), ptr(g), ptr(coef), B, g.shape[1],
+                                                  dtype_code(g), 0, ptr(self._slice(S, m.weight)),
+                                                  ptr(self._slice(S, m.bias)), st),
+                      "vqaf_clipped_sum_affine")
+        return S
+
+    @torch.no_grad()
+    def add_noise_and_scale(self, noise: Optional[torch.Tensor] = None):
+        """grad = (S + sigma C z) / expected_batch_size.  In a process group every rank adds its
+        own N(0, (sigma C)^2 / world) share BEFORE the all-reduce, so the sum carries exactly
+        one N(0, (sigma C)^2).  `noise` injects z (tests)."""
+        import torch.distributed as dist
+        S, grad = self._S, self._grad
+        world, rank = self._world()
+        std = self.noise_multiplier * self.max_grad_norm / math.sqrt(world)
+        check(load().vqaf_noise_scale(ptr(S), ptr(noise), ptr(self._rng.state), std,
+                                      1.0 / self.expected_batch_size, self._numel, ptr(grad),
+                                      stream_ptr(S.device)), "vqaf_noise_scale")
+        if noise is None and std != 0.0:
+            self._rng.advance()
+        if world > 1:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.process_group)
+        return grad
+
+    def pre_step(self, noise: Optional[torch.Tensor] = None):
+        self.clip_and_accumulate()
+        self.add_noise_and_scale(noise)
+        if self.accountant_hook is not None:
+            self.accountant_hook(self)
+
+    def step(self, closure=None):
+        self.pre_step()
+        for t in self.module.tapes:  # a second step() without a new backward must fail loudly
+            t.g = None
+        return self.original_optimizer.step()
+
+    def flat_noise_layout(self):
+        """(name-less) list of (offset, numel, shape) per parameter in the flat buffers."""
+        return [(self._offsets[id(p)], p.numel(), tuple(p.shape)) for p in self.params]
+
+
+# --------------------------------------------------------------------------------------------
+# Poisson-sampled loader and the engine
+# --------------------------------------------------------------------------------------------
+class PoissonBatchSampler(torch.utils.data.Sampler):
+    """Each step includes every sample independently with probability sample_rate
+    (Opacus UniformWithReplacementSampler); batches may be empty."""
+
+    def __init__(self, num_samples: int, sample_rate: float, steps: Optional[int] = None,
+                 generator: Optional[torch.Generator] = None):
+        self.num_samples, self.sample_rate = int(num_samples), float(sample_rate)
+        self.steps = int(steps) if steps is not None else int(round(1.0 / sample_rate))
+        self.generator = generator
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            mask = torch.rand(self.num_samples, generator=self.generator) < self.sample_rate
+            yield mask.nonzero(as_tuple=False).reshape(-1).tolist()
+
+
+class DPDataLoader(torch.utils.data.DataLoader):
+    """DataLoader over the same dataset with Poisson batches (make_private(poisson_sampling=True))."""
+
+    @classmethod
+    def from_data_loader(cls, dl: torch.utils.data.DataLoader, generator=None):
+        sample_rate = 1.0 / len(dl)
+        sampler = PoissonBatchSampler(len(dl.dataset), sample_rate, steps=len(dl), generator=generator)
+        collate = dl.collate_fn
+
+        def collate_skip_empty(batch):
+            return collate(batch) if len(batch) > 0 else None
+
+        out = cls(dl.dataset, batch_sampler=sampler, num_workers=dl.num_workers,
+                  collate_fn=collate_skip_empty, pin_memory=dl.pin_memory)
+        out.sample_rate = sample_rate
+        return out
+
+
+class PrivacyEngine:
+    """make_private / make_private_with_epsilon / get_epsilon as used at train.py:127-153, 209."""
+
+    def __init__(self, *, accountant: str = "rdp", secure_mode: bool = False):
+        if accountant != "rdp":
+            raise ValueError("only the RDP accountant is implemented")
+        if secure_mode:
+            raise ValueError("secure_mode (cryptographic RNG) is not implemented; the reference "
+                             "passes secure_mode=False (train.py:127)")
+        self.accountant = RDPAccountant()
+        self.secure_mode = secure_mode
+
+    def make_private(self, *, module: nn.Module, optimizer: torch.optim.Optimizer, data_loader,
+                     noise_multiplier: float, max_grad_norm: float, batch_first: bool = True,
+                     loss_reduction: str = "mean", poisson_sampling: bool = True,
+                     noise_generator=None, seed: Optional[int] = None, process_group=None):
+        if isinstance(module, GradSampleModule):
+            gsm = module
+        else:
+            gsm = GradSampleModule(module, batch_first=batch_first, loss_reduction=loss_reduction)
+        if data_loader is not None:
+            sample_rate = 1.0 / len(data_loader)
+            expected = int(len(data_loader.dataset) * sample_rate)
+            loader = DPDataLoader.from_data_loader(data_loader) if poisson_sampling else data_loader
+        else:
+            sample_rate, expected, loader = None, None, None
+        world = 1
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(process_group)
+        if expected is None:
+            raise ValueError("data_loader is required to derive sample_rate and expected_batch_size")
+        dp_opt = DPOptimizer(optimizer, gsm, noise_multiplier=noise_multiplier,
+                             max_grad_norm=max_grad_norm, expected_batch_size=expected * world,
+                             seed=seed, process_group=process_group)
+        self.sample_rate = sample_rate
+        dp_opt.attach_step_hook(
+            lambda _o: self.accountant.step(noise_multiplier=noise_multiplier, sample_rate=sample_rate))
+        return gsm, dp_opt, loader
+
+    def make_private_with_epsilon(self, *, module, optimizer, data_loader, target_epsilon: float,
+                                  target_delta: float, epochs: int, max_grad_norm: float,
+                                  batch_first: bool = True, loss_reduction: str = "mean",
+                                  poisson_sampling: bool = True, **kwargs):
+        sample_rate = 1.0 / len(data_loader)
+        sigma = get_noise_multiplier(target_epsilon=target_epsilon, target_delta=target_delta,
+                                     sample_rate=sample_rate, steps=int(epochs * len(data_loader)))
+        return self.make_private(module=module, optimizer=optimizer, data_loader=data_loader,
+                                 noise_multiplier=sigma, max_grad_norm=max_grad_norm,
+                                 batch_first=batch_first, loss_reduction=loss_reduction,
+                                 poisson_sampling=poisson_sampling, **kwargs)
+
+    def get_epsilon(self, delta: float) -> float:
+        return self.accountant.get_epsilon(delta)

@@ -52,6 +52,16 @@ def default_rng(device: torch.device) -> PhiloxState:
     return st[1]
 
 
+# Optional measurement probe: bench.py installs a callable (name, phase) -> None that records
+# stream events around a named kernel launch; None in normal use.
+PROBE = None
+
+
+def _probe(name: str, phase: str) -> None:
+    if PROBE is not None:
+        PROBE(name, phase)
+
+
 def _noise_kind(noise_type: Optional[str]) -> int:
     if noise_type is None:
         return _lib.NOISE_NONE
@@ -223,10 +233,12 @@ class _PrunedPool(torch.autograd.Function):
             K = idx.shape[1]
             seq_c, idx_c = seq.contiguous(), idx.contiguous()
             noise_c = noise.to(torch.float32).contiguous() if noise is not None else None
+            _probe(f"gather_mix_pool:{len(saved)}", "begin")
             check(lib.vqaf_gather_mix_pool(ptr(seq_c), ptr(idx_c), ptr(noise_c), kind, float(scale),
                                            ptr(state), float(alpha), B, N, K, D, dtype_code(seq_c),
                                            ptr(out), ld, col0, dtype_code(out), stream_ptr(dev)),
                   "vqaf_gather_mix_pool")
+            _probe(f"gather_mix_pool:{len(saved)}", "end")
             if state is not None:  # next consumer gets a fresh stream
                 check(lib.vqaf_rng_advance(ptr(state), 1, stream_ptr(dev)), "vqaf_rng_advance")
             saved.append(idx_c)
@@ -286,6 +298,28 @@ def ce_conf(logits: torch.Tensor, targets: Optional[torch.Tensor] = None, want_l
     check(load().vqaf_ce_conf(ptr(lg), ptr(tg), B, C, dtype_code(lg), ptr(loss), ptr(conf), ptr(pred),
                               ptr(grad), float(grad_scale or 0.0), stream_ptr(dev)), "vqaf_ce_conf")
     return loss, conf, pred, grad
+
+
+class _MeanCE(torch.autograd.Function):
+    """Mean cross-entropy (nn.CrossEntropyLoss() as the training loop uses it, train.py:104,
+    utils/src.py:96) with its logits gradient produced by the same kernel launch."""
+
+    @staticmethod
+    def forward(ctx, logits, targets):
+        B = logits.shape[0]
+        loss, _, _, grad = ce_conf(logits, targets, want_loss=True, want_conf=False, grad_scale=1.0 / B)
+        ctx.save_for_backward(grad)
+        ctx.in_dtype = logits.dtype
+        return loss.mean()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grad,) = ctx.saved_tensors
+        return (grad * grad_out).to(ctx.in_dtype), None
+
+
+def cross_entropy_mean(logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    return _MeanCE.apply(logits, targets)
 
 
 def keep_count(n_tokens: int, prune_ratio: float) -> int:
