@@ -63,19 +63,24 @@ const char* vqaf_status_string(int status);
  * ------------------------------------------------------------------------------------ */
 
 /* u (B,H,D) f32  <-  q (B,D) `dtype`, in_proj_weight (3D,D) / in_proj_bias (3D) `w_dtype`.
- * `qproj_ws` is a (B,D) f32 workspace. */
+ * `qproj_ws` is a (B,D) f32 workspace.  If `u_split` is non-NULL (and H <= 8) it also receives
+ * u as two bf16 terms, (B,16,D) bf16 with rows 0..7 = bf16(u_h) and rows 8..15 =
+ * bf16(u_h - bf16(u_h)): the B operand of the bf16 matrix-core scoring kernel, whose sum
+ * carries ~16 mantissa bits of u. */
 int vqaf_fold_query(const void* q, const void* in_proj_weight, const void* in_proj_bias,
                     int B, int D, int H, int dtype, int w_dtype, float* qproj_ws, float* u,
-                    vqaf_stream_t stream);
+                    void* u_split, vqaf_stream_t stream);
 
-/* s (B,N,H) f32  <-  seq (B,N,D) `dtype`, u (B,H,D) f32.  Raw per-head scaled scores. */
-int vqaf_head_scores(const void* seq, const float* u, int B, int N, int D, int H, int dtype,
-                     float* s, vqaf_stream_t stream);
+/* s (B,N,H) f32  <-  seq (B,N,D) `dtype`, u (B,H,D) f32.  Raw per-head scaled scores.
+ * With bf16 tokens, H <= 8, D in {64,128,256,512,768,1024} and a non-NULL `u_split` the
+ * products run on bf16 MFMA (tokens exact, u to ~2^-17); otherwise on the f32 vector ALU. */
+int vqaf_head_scores(const void* seq, const float* u, const void* u_split, int B, int N, int D,
+                     int H, int dtype, float* s, vqaf_stream_t stream);
 
 /* w (B,N) f32  <-  s (B,N,H) f32: softmax over n per head, then mean over heads. */
 int vqaf_attn_weights(const float* s, int B, int N, int H, float* w, vqaf_stream_t stream);
 
-/* Bytes of workspace vqaf_score needs (qproj + u + s), 256-byte aligned pieces. */
+/* Bytes of workspace vqaf_score needs (qproj + u + u_split + s), 256-byte aligned pieces. */
 size_t vqaf_score_workspace_bytes(int B, int N, int D, int H);
 
 /* The three steps above in one call: w (B,N) f32 <- q, seq, in_proj_{weight,bias}. */

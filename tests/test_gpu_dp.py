@@ -74,7 +74,7 @@ def test_dp_step_f32_vs_oracle(dev, in_dim, hidden, C, B, max_norm):
     got = _flat_to_named(opt, gsm, S)
     for n, want in sums.items():
         scale = max(1e-6, float(want.abs().max()))
-        np.testing.assert_allclose(got["_module." + n].numpy(), want.numpy(), rtol=rtol_n, atol=20 * rtol_n * scale / 100,
+        np.testing.assert_allclose(got["_module." + n].numpy(), want.numpy(), rtol=rtol_n, atol=(2e-6 if hidden >= 256 else 1e-4) * scale,
                                    err_msg=n)
     # noise + scale with the injected draw
     flat_z = torch.zeros(opt._numel)
@@ -84,11 +84,13 @@ def test_dp_step_f32_vs_oracle(dev, in_dim, hidden, C, B, max_norm):
     for n, p in gsm.named_parameters():
         want = grads[n.replace("_module.", "")]
         scale = max(1e-6, float(want.abs().max()))
-        np.testing.assert_allclose(p.grad.cpu().numpy(), want.numpy(), rtol=rtol_n, atol=20 * rtol_n * scale / 100, err_msg=n)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want.numpy(), rtol=rtol_n, atol=(2e-6 if hidden >= 256 else 1e-4) * scale, err_msg=n)
     # input gradient (flows on to the non-private fusion / encoders): plain autograd value
     cx = x.clone().requires_grad_()
     nn.CrossEntropyLoss()(cpu_m(cx), y).backward()
-    np.testing.assert_allclose(xg.grad.cpu().numpy(), cx.grad.numpy(), rtol=1e-4, atol=1e-7)
+    gscale = float(cx.grad.abs().max())
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), cx.grad.numpy(), rtol=1e-4,
+                               atol=(1e-5 if hidden >= 256 else 2e-4) * gscale)
     np.testing.assert_allclose(logits.detach().cpu().numpy(), cpu_m(x).detach().numpy(), rtol=1e-4, atol=1e-5)
 
 
@@ -112,11 +114,28 @@ def test_dp_kernels_bf16_same_inputs(dev):
     Sb = torch.empty(Out, device=dev)
     check(lib.vqaf_clipped_sum_linear(ptr(ad), ptr(gd), ptr(cd), B, In, Out, BF16, 0, ptr(SW), ptr(Sb), st), "cs")
     wantW = torch.einsum("b,bo,bi->oi", coef.double(), gf, af)
-    np.testing.assert_allclose(SW.cpu().numpy(), wantW.numpy(), rtol=1e-2, atol=1e-6)
-    np.testing.assert_allclose(Sb.cpu().numpy(), (coef.double()[:, None] * gf).sum(0).numpy(), rtol=1e-2, atol=1e-6)
+    # coef * g is re-rounded to bf16 before the MFMA (2^-9 per element), so entries that are
+    # sums with cancellation need an absolute term tied to the size of the matrix
+    wscale = float(wantW.abs().max())
+    np.testing.assert_allclose(SW.cpu().numpy(), wantW.numpy(), rtol=1e-2, atol=2e-3 * wscale)
+    assert float((SW.cpu().double() - wantW).norm() / wantW.norm()) < 3e-3
+    np.testing.assert_allclose(Sb.cpu().numpy(), (coef.double()[:, None] * gf).sum(0).numpy(), rtol=1e-5, atol=1e-7)
     # accumulate flag adds a second micro-batch
     check(lib.vqaf_clipped_sum_linear(ptr(ad), ptr(gd), ptr(cd), B, In, Out, BF16, 1, ptr(SW), ptr(Sb), st), "cs")
-    np.testing.assert_allclose(SW.cpu().numpy(), 2 * wantW.numpy(), rtol=1e-2, atol=1e-6)
+    np.testing.assert_allclose(SW.cpu().numpy(), 2 * wantW.numpy(), rtol=1e-2, atol=4e-3 * wscale)
+    # odd row pitches take the narrower load paths
+    for (B2, In2, Out2) in ((70, 200, 430), (9, 66, 13), (33, 65, 7)):
+        a2, g2 = gi.normal(11, B2, In2).bfloat16(), gi.normal(12, B2, Out2).bfloat16()
+        c2 = torch.rand(B2) + 0.5
+        a2d, g2d, c2d = a2.to(dev), g2.to(dev), c2.to(dev)
+        SW2 = torch.empty(Out2, In2, device=dev)
+        Sb2 = torch.empty(Out2, device=dev)
+        check(lib.vqaf_clipped_sum_linear(ptr(a2d), ptr(g2d), ptr(c2d), B2, In2, Out2, BF16, 0, ptr(SW2),
+                                          ptr(Sb2), st), "cs")
+        w2 = torch.einsum("b,bo,bi->oi", c2.double(), g2.double(), a2.double())
+        np.testing.assert_allclose(SW2.cpu().numpy(), w2.numpy(), rtol=1e-2, atol=4e-3 * float(w2.abs().max()))
+        np.testing.assert_allclose(Sb2.cpu().numpy(), (c2.double()[:, None] * g2.double()).sum(0).numpy(),
+                                   rtol=1e-5, atol=1e-6)
     # GroupNorm + ReLU forward / backward in bf16 storage
     C, groups = 2048, 32
     x = gi.normal(3, B, C).bfloat16()

@@ -82,6 +82,43 @@ def test_scores_other_head_counts_and_dims(dev):
         np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=3e-5, atol=1e-8)
 
 
+def test_small_gemm_strides_and_dtypes(dev):
+    """vqaf_gemm_f32: every staging mode (contiguous along k, along m/n, neither), ragged sizes,
+    batching, bias, alpha and accumulate, against f64 matmul."""
+    from vqa_amd._lib import check, dtype_code, load, ptr, stream_ptr
+    lib, st = load(), stream_ptr(dev)
+
+    def run(A, Bm, bias, G, M, N, K, sa, sb, alpha=1.0, beta_one=0, C0=None):
+        C = torch.zeros(G, M, N, device=dev) if C0 is None else C0.clone()
+        check(lib.vqaf_gemm_f32(ptr(A), dtype_code(A), *sa, ptr(Bm), dtype_code(Bm), *sb,
+                                ptr(bias), dtype_code(bias) if bias is not None else 0, N if bias is not None else 0,
+                                ptr(C), M * N, N, G, M, N, K, alpha, beta_one, st), "gemm")
+        return C
+
+    for (G, M, N, K) in ((1, 70, 130, 100), (3, 64, 64, 32), (2, 33, 17, 5), (1, 128, 512, 512)):
+        for dt in (torch.float32, torch.bfloat16):
+            A = gi.normal(1 + M, G, M, K).to(dt).to(dev)          # [g][m][k]: k contiguous
+            Bkn = gi.normal(2 + N, G, K, N).to(dt).to(dev)        # [g][k][n]: n contiguous
+            bias = gi.normal(3, G, N).to(dt).to(dev)
+            want = torch.matmul(A.double(), Bkn.double()) * 0.5 + bias.double()[:, None, :]
+            got = run(A, Bkn, bias, G, M, N, K, (M * K, K, 1), (K * N, N, 1), alpha=0.5)
+            tol = 2e-6 * float(want.abs().max())  # f32 accumulation over K terms
+            np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=tol)
+            At = A.transpose(1, 2).contiguous()                   # [g][k][m]: m contiguous
+            Bnk = Bkn.transpose(1, 2).contiguous()                # [g][n][k]: k contiguous
+            got2 = run(At, Bnk, None, G, M, N, K, (M * K, 1, M), (K * N, 1, K))
+            want2 = torch.matmul(A.double(), Bkn.double())
+            np.testing.assert_allclose(got2.cpu().numpy(), want2.cpu().numpy(), rtol=2e-5, atol=2 * tol)
+            got3 = run(At, Bnk, None, G, M, N, K, (M * K, 1, M), (K * N, 1, K), beta_one=1, C0=got2)
+            np.testing.assert_allclose(got3.cpu().numpy(), 2 * want2.cpu().numpy(), rtol=2e-5, atol=4 * tol)
+    # neither index contiguous: every second element of a wider buffer
+    A = gi.normal(9, 40, 2 * 24).to(dev)
+    Bm = gi.normal(10, 24, 2 * 50).to(dev)
+    got = run(A, Bm, None, 1, 40, 50, 24, (0, 48, 2), (0, 100, 2))
+    want = A[:, ::2].double() @ Bm[:, ::2].double()
+    np.testing.assert_allclose(got[0].cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
 # ------------------------------------------------------------------ top-k (a2)
 @pytest.mark.parametrize("name", _names("prune_"))
 def test_topk_bit_exact_vs_golden(dev, name):

@@ -25,8 +25,8 @@ _P = c_void_p
 SIGNATURES = {
     "vqaf_version": (c_int, []),
     "vqaf_status_string": (c_char_p, [c_int]),
-    "vqaf_fold_query": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
-    "vqaf_head_scores": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vqaf_fold_query": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "vqaf_head_scores": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "vqaf_attn_weights": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "vqaf_score_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vqaf_score": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t,

@@ -136,31 +136,233 @@ clipped_sum_linear_kernel(const void* __restrict__ a, const void* __restrict__ g
   }
 }
 
+// bf16 operands: the same batch contraction on v_mfma_f32_32x32x16_bf16.
+// Both operands are stored batch-major ((B,Out) and (B,In)), i.e. the contraction index is the
+// SLOW index of both, while an MFMA lane needs 8 consecutive k for one row/column.  The tiles are
+// therefore staged into LDS exactly as they lie in memory ([k][column], 16-byte row chunks, rows
+// padded by 64 B so that the four k-rows of a transposed read fall on disjoint bank groups) and
+// the fragments are fetched with ds_read_b64_tr_b16, the hardware transposing read: a 16-lane
+// group reads a 4(k) x 16(column) block and each lane receives one column's four k values.
+// Workgroup tile 128 (Out) x 64 (In), four waves of 64 x 32 (2 x 1 MFMA tiles), 32 batch rows per
+// stage.  Staging goes through registers two stages ahead (loads of stage s+2 are in flight while
+// stage s is multiplied), the coefficient is applied while stage s+1 moves from registers to LDS
+// (the product is re-rounded to bf16 by v_cvt_pk_bf16_f32).
+constexpr int CB_TM = 128;
+constexpr int CB_TN = 64;
+constexpr int CB_KB = 32;
+constexpr int CB_PG = CB_TM + 32;  // LDS row pitch of the g tile (elements)
+constexpr int CB_PA = CB_TN + 32;  // LDS row pitch of the a tile
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int PITCH>
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int kblock, int col0, int lane) {
+  // lane 4q+p of each 16-lane group addresses row kblock+q, columns col0 + 4p .. 4p+3
+  const int i = lane & 15;
+  const bf16_t* p0 = tile + (kblock + (i >> 2)) * PITCH + col0 + 4 * (i & 3);
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0 + 4 * PITCH));
+  union { s16x8 s; bf16x8 b; } u;
+  u.s = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return u.b;
+}
+
+// 8 consecutive bf16 of row `row` from column `col` (zeros outside the matrix).
+// VEC = elements per load instruction the row pitch allows: 8 (16 B), 2 (4 B) or 1.
+template <int VEC>
+__device__ __forceinline__ u32x4 load_row8(const bf16_t* base, int row, int nrows, int col, int ncols) {
+  u32x4 r = u32x4{0u, 0u, 0u, 0u};
+  if (row >= nrows) return r;
+  const bf16_t* p = base + (size_t)row * ncols + col;
+  if constexpr (VEC == 8) {
+    if (col < ncols) r = *reinterpret_cast<const u32x4*>(p);
+  } else if constexpr (VEC == 2) {
+    const unsigned int* q = reinterpret_cast<const unsigned int*>(p);
+    unsigned int w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (col + 2 * e < ncols) w[e] = q[e];
+    r = u32x4{w[0], w[1], w[2], w[3]};
+  } else {
+    unsigned int w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (col + e < ncols) w[e >> 1] |= ((unsigned int)p[e]) << ((e & 1) * 16);
+    r = u32x4{w[0], w[1], w[2], w[3]};
+  }
+  return r;
+}
+
+__device__ __forceinline__ unsigned int scale_pack2(unsigned int w, float c, float& s0, float& s1) {
+  const float lo = bf16_lo(w) * c, hi = bf16_hi(w) * c;
+  s0 += lo;
+  s1 += hi;
+  union { bf16x2 b; unsigned int u; } cv;
+  cv.b = bf16x2{(__bf16)lo, (__bf16)hi};
+  return cv.u;
+}
+
+template <int VEC_G, int VEC_A>
+__global__ void __launch_bounds__(DP_THREADS)
+clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ g,
+                               const float* __restrict__ coef, int B, int In, int Out,
+                               int accumulate, float* __restrict__ SW, float* __restrict__ Sb) {
+  __shared__ __attribute__((aligned(16))) bf16_t ldg[2][CB_KB][CB_PG];
+  __shared__ __attribute__((aligned(16))) bf16_t lda[2][CB_KB][CB_PA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * CB_TM, n0 = blockIdx.x * CB_TN;
+  const int gr = tid >> 4, gc = (tid & 15) * 8;  // g tile: rows gr, gr+16; 8 columns from gc
+  const int ar = tid >> 3, ac = (tid & 7) * 8;   // a tile: row ar; 8 columns from ac
+  const bool do_bias = (Sb != nullptr) && (blockIdx.x == 0);
+  const int g16 = lane >> 4;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+  // two register sets; stage t lives in set t & 1
+  u32x4 rg[2][2], ra[2];
+  float rc[2][2];
+  const int stages = (B + CB_KB - 1) / CB_KB;
+
+#define CB_FETCH(SET, T)                                                              \
+  do {                                                                                \
+    const int k0_ = (T) * CB_KB;                                                      \
+    _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                \
+      const int row = k0_ + gr + 16 * ps;                                             \
+      rg[SET][ps] = load_row8<VEC_G>(g, row, B, m0 + gc, Out);                        \
+      rc[SET][ps] = row < B ? coef[row] : 0.f;                                        \
+    }                                                                                 \
+    ra[SET] = load_row8<VEC_A>(a, k0_ + ar, B, n0 + ac, In);                          \
+  } while (0)
+#define CB_STASH(SET, BUF)                                                            \
+  do {                                                                                \
+    _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                \
+      const float c = rc[SET][ps];                                                    \
+      u32x4 v = rg[SET][ps];                                                          \
+      v.x = scale_pack2(v.x, c, bsum[0], bsum[1]);                                    \
+      v.y = scale_pack2(v.y, c, bsum[2], bsum[3]);                                    \
+      v.z = scale_pack2(v.z, c, bsum[4], bsum[5]);                                    \
+      v.w = scale_pack2(v.w, c, bsum[6], bsum[7]);                                    \
+      *reinterpret_cast<u32x4*>(&ldg[BUF][gr + 16 * ps][gc]) = v;                     \
+    }                                                                                 \
+    *reinterpret_cast<u32x4*>(&lda[BUF][ar][ac]) = ra[SET];                           \
+  } while (0)
+
+  CB_FETCH(0, 0);
+  if (stages > 1) CB_FETCH(1, 1);
+  CB_STASH(0, 0);
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < stages; s += 2) {
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      const int t = s + P;
+      if (t < stages) {
+        if (t + 2 < stages) CB_FETCH(P, t + 2);  // set P is free: stage t already sits in LDS
+        const bf16_t* tg = &ldg[P][0][0];
+        const bf16_t* ta = &lda[P][0][0];
+#pragma unroll
+        for (int ks = 0; ks < CB_KB / 16; ++ks) {
+          const int kblock = 16 * ks + 8 * (g16 >> 1);
+          const bf16x8 bfv = tr_frag<CB_PA>(ta, kblock, wn * 32 + 16 * (g16 & 1), lane);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const bf16x8 afv = tr_frag<CB_PG>(tg, kblock, wm * 64 + i * 32 + 16 * (g16 & 1), lane);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afv, bfv, acc[i], 0, 0, 0);
+          }
+        }
+        if (t + 1 < stages) CB_STASH(P ^ 1, P ^ 1);
+        __syncthreads();
+      }
+    }
+  }
+#undef CB_FETCH
+#undef CB_STASH
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int n = n0 + wn * 32 + (lane & 31);
+      if (m < Out && n < In) {
+        float* p = SW + (size_t)m * In + n;
+        *p = accumulate ? *p + acc[i][r] : acc[i][r];
+      }
+    }
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(&ldg[0][0][0]);  // 16 x 128 f32 = 8 KiB; the loop is done
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[gr * CB_TM + gc + e] = bsum[e];
+    __syncthreads();
+    if (tid < CB_TM && m0 + tid < Out) {
+      float v = 0.f;
+      for (int r = 0; r < 16; ++r) v += red[r * CB_TM + tid];
+      Sb[m0 + tid] = accumulate ? Sb[m0 + tid] + v : v;
+    }
+  }
+}
+
 // Sgamma[c] (+)= sum_b coef[b] xhat[b,c] g[b,c];  Sbeta[c] (+)= sum_b coef[b] g[b,c].
+// Grid (column blocks of 128, batch chunks of AF_ROWS): a workgroup sums its chunk with 16-byte
+// loads (16 lanes per row, 16 rows in flight), folds the 16 row groups in LDS in a fixed order and
+// adds its 128 partial sums to the output with one f32 atomic per column.  The outputs are zeroed
+// first when accumulate == 0.  (The order of the few atomic adds per column is not fixed, so the
+// last bits of these sums may differ from run to run.)
+constexpr int AF_ROWS = 64;
 template <bool BF16>
 __global__ void __launch_bounds__(DP_THREADS)
 clipped_sum_affine_kernel(const void* __restrict__ xhat, const void* __restrict__ g,
-                          const float* __restrict__ coef, int B, int C, int accumulate,
+                          const float* __restrict__ coef, int B, int C,
                           float* __restrict__ Sgamma, float* __restrict__ Sbeta) {
-  __shared__ float r0[4][64], r1[4][64];
-  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + col;
-  float sg = 0.f, sb = 0.f;
-  if (c < C) {
-    for (int b = rg; b < B; b += 4) {
-      const float gv = coef[b] * load1<BF16>(g, (size_t)b * C + c);
-      sg = fmaf(load1<BF16>(xhat, (size_t)b * C + c), gv, sg);
-      sb += gv;
+  __shared__ float r0[16][128], r1[16][128];
+  const int tid = threadIdx.x, r16 = tid >> 4, cc = (tid & 15) * 8;
+  const int c0 = blockIdx.x * 128 + cc;
+  const int b0 = blockIdx.y * AF_ROWS;
+  float sg[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sg[e] = sb[e] = 0.f;
+  if (c0 < C) {
+#pragma unroll
+    for (int i = 0; i < AF_ROWS / 16; ++i) {
+      const int b = b0 + r16 + 16 * i;
+      if (b < B) {
+        float gv[8], xv[8];
+        load8<BF16>(g, (size_t)b * C + c0, gv);
+        load8<BF16>(xhat, (size_t)b * C + c0, xv);
+        const float c = coef[b];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = c * gv[e];
+          sg[e] = fmaf(xv[e], t, sg[e]);
+          sb[e] += t;
+        }
+      }
     }
   }
-  r0[rg][col] = sg;
-  r1[rg][col] = sb;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    r0[r16][cc + e] = sg[e];
+    r1[r16][cc + e] = sb[e];
+  }
   __syncthreads();
-  if (threadIdx.x < 64 && c < C) {
-    const float vg = (r0[0][col] + r0[1][col]) + (r0[2][col] + r0[3][col]);
-    const float vb = (r1[0][col] + r1[1][col]) + (r1[2][col] + r1[3][col]);
-    if (Sgamma != nullptr) Sgamma[c] = accumulate ? Sgamma[c] + vg : vg;
-    if (Sbeta != nullptr) Sbeta[c] = accumulate ? Sbeta[c] + vb : vb;
+  if (tid < 128 && blockIdx.x * 128 + tid < C) {
+    float vg = 0.f, vb = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      vg += r0[r][tid];
+      vb += r1[r][tid];
+    }
+    const int c = blockIdx.x * 128 + tid;
+    if (Sgamma != nullptr) atomicAdd(Sgamma + c, vg);
+    if (Sbeta != nullptr) atomicAdd(Sbeta + c, vb);
   }
 }
 
@@ -429,10 +631,33 @@ extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float
   VQAF_REQUIRE(a && g && coef && SW, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && In > 0 && Out > 0, VQAF_E_SHAPE);
+  if (dtype == VQAF_BF16) {
+    const dim3 grid((In + CB_TN - 1) / CB_TN, (Out + CB_TM - 1) / CB_TM);
+    VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);
+    const bf16_t* ab = reinterpret_cast<const bf16_t*>(a);
+    const bf16_t* gb = reinterpret_cast<const bf16_t*>(g);
+    auto vec_of = [](const void* p, int pitch) {
+      if (pitch % 8 == 0 && vqaf_aligned16(p)) return 8;
+      if (pitch % 2 == 0 && (reinterpret_cast<uintptr_t>(p) & 3u) == 0) return 2;
+      return 1;
+    };
+    const int vg = vec_of(g, Out), va = vec_of(a, In);
+    hipStream_t st = (hipStream_t)stream;
+#define VQAF_CSB(VG, VA)                                                                         \
+  hipLaunchKernelGGL((clipped_sum_linear_bf16_kernel<VG, VA>), grid, dim3(DP_THREADS), 0, st, ab, \
+                     gb, coef, B, In, Out, accumulate, SW, Sb)
+    if (vg == 8 && va == 8) VQAF_CSB(8, 8);
+    else if (vg == 2 && va == 8) VQAF_CSB(2, 8);
+    else if (vg == 8 && va == 2) VQAF_CSB(8, 2);
+    else if (vg == 2 && va == 2) VQAF_CSB(2, 2);
+    else VQAF_CSB(1, 1);
+#undef VQAF_CSB
+    VQAF_LAUNCH_CHECK();
+  }
   const dim3 grid((In + CS_T - 1) / CS_T, (Out + CS_T - 1) / CS_T);
   VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);
-  VQAF_BY_DTYPE(clipped_sum_linear_kernel, grid, dim3(DP_THREADS), (hipStream_t)stream, a, g, coef,
-                B, In, Out, accumulate, SW, Sb);
+  hipLaunchKernelGGL(clipped_sum_linear_kernel<false>, grid, dim3(DP_THREADS), 0,
+                     (hipStream_t)stream, a, g, coef, B, In, Out, accumulate, SW, Sb);
   VQAF_LAUNCH_CHECK();
 }
 
@@ -442,8 +667,16 @@ extern "C" int vqaf_clipped_sum_affine(const void* xhat, const void* g, const fl
   VQAF_REQUIRE(xhat && g && coef, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && C > 0, VQAF_E_SHAPE);
-  VQAF_BY_DTYPE(clipped_sum_affine_kernel, dim3((C + 63) / 64), dim3(DP_THREADS),
-                (hipStream_t)stream, xhat, g, coef, B, C, accumulate, Sgamma, Sbeta);
+  VQAF_REQUIRE(C % 8 == 0 && vqaf_aligned16(xhat) && vqaf_aligned16(g), VQAF_E_ALIGN);
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    if (Sgamma != nullptr && hipMemsetAsync(Sgamma, 0, (size_t)C * 4, st) != hipSuccess) return VQAF_E_LAUNCH;
+    if (Sbeta != nullptr && hipMemsetAsync(Sbeta, 0, (size_t)C * 4, st) != hipSuccess) return VQAF_E_LAUNCH;
+  }
+  const dim3 grid((C + 127) / 128, (B + AF_ROWS - 1) / AF_ROWS);
+  VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);
+  VQAF_BY_DTYPE(clipped_sum_affine_kernel, grid, dim3(DP_THREADS), st, xhat, g, coef, B, C, Sgamma,
+                Sbeta);
   VQAF_LAUNCH_CHECK();
 }
 
