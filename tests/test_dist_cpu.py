@@ -1,0 +1,89 @@
+"""CPU rehearsal of the data-parallel DP-SGD exchange: two gloo ranks, each computing the
+clipped sums of its shard with the oracle, reduced with vqa_amd.dist exactly as DPOptimizer does
+(sum all-reduce of the flat bucket, noise split N(0, (sigma C)^2 / world) per rank)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import dp_oracle as do
+from oracle import inputs as gi
+from vqa_amd import dist as vdist
+
+IN, HID, C, B = 64, 64, 13, 12
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model():
+    m = do.make_classifier(IN, HID, C, dp_fixed=True)
+    m.load_state_dict(gi.classifier_params(50, IN, HID, C))
+    return m.eval()
+
+
+def _flat(d):
+    return torch.cat([d[k].reshape(-1) for k in sorted(d)])
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    r, _, w = vdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    x, y = gi.normal(1, B, IN), gi.labels(2, B, C)
+    lo, hi = vdist.shard_range(B, rank, world)
+    sigma, clip = 1.0, 1.0
+    _, _, sums, _ = do.dp_step(_model(), x[lo:hi], y[lo:hi], clip, 0.0, B)
+    bucket = _flat(sums)
+    # every rank adds its own share of the noise before the reduce (rank-seeded stream)
+    std = vdist.per_rank_noise_std(sigma, clip, world)
+    gen = torch.Generator().manual_seed(1234 + rank)
+    noise = torch.randn(bucket.shape, generator=gen) * std
+    reduced = vdist.allreduce_sum_((bucket + noise) / B)
+    noise_total = vdist.allreduce_sum_(noise.clone())
+    vdist.barrier()
+    if rank == 0:
+        torch.save({"reduced": reduced, "noise_total": noise_total}, os.path.join(out_dir, "r0.pt"))
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    for n in (1, 7, 1024, 200000):
+        for world in (1, 2, 3, 8):
+            parts = [vdist.shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+    assert vdist.shard_range(1024, 3, 8) == (384, 512)
+
+
+def test_noise_split_adds_up():
+    for world in (1, 2, 4, 8):
+        std = vdist.per_rank_noise_std(1.3, 0.7, world)
+        assert abs(world * std ** 2 - (1.3 * 0.7) ** 2) < 1e-12
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "r0.pt"), weights_only=True)
+    x, y = gi.normal(1, B, IN), gi.labels(2, B, C)
+    _, _, sums, _ = do.dp_step(_model(), x, y, 1.0, 0.0, B)
+    want = _flat(sums) / B
+    # per-sample clipping is rank-local, so shard sums add up to the full-batch sum
+    np.testing.assert_allclose((got["reduced"] - got["noise_total"] / B).numpy(), want.numpy(),
+                               rtol=1e-5, atol=1e-7)
+    # the summed noise has variance (sigma C)^2: 2 shares of variance 1/2 each
+    n = got["noise_total"]
+    assert abs(float(n.std()) - 1.0) < 5.0 / n.numel() ** 0.5 + 0.05

@@ -43,3 +43,57 @@ def test_unknown_noise_type_raises_like_reference():
     p = fusion.PrivacyAwareTokenPruning(noise_type="laplace")
     with pytest.raises(ValueError, match="Unsupported noise type"):
         p._noise_args(None)
+
+
+def test_rdp_accountant_known_values():
+    """Subsampled-Gaussian RDP against closed forms and the widely quoted MNIST setting
+    (q = 256/60000, sigma = 1.1, 60 epochs, delta = 1e-5 -> eps = 3.01 with the classic
+    RDP->DP conversion)."""
+    import math
+    from vqa_amd import accountant as acc
+    # q = 1: plain Gaussian mechanism, rdp(alpha) = alpha / (2 sigma^2)
+    assert acc.compute_rdp(1.0, 2.0, 1, [2.0, 2.5]) == [0.25, 0.3125]
+    assert acc.compute_rdp(0.0, 1.0, 10, [2.0]) == [0.0]
+    q, steps = 256 / 60000, int(60 * 60000 / 256)
+    rdp = acc.compute_rdp(q, 1.1, steps)
+    classic = min(r + math.log(1e5) / (a - 1) for r, a in zip(rdp, acc.DEFAULT_ALPHAS))
+    assert abs(classic - 3.008) < 5e-3
+    eps, alpha = acc.rdp_to_epsilon(rdp, acc.DEFAULT_ALPHAS, 1e-5)
+    assert 2.4 < eps < classic and alpha > 1
+    # integer and fractional order formulas agree where they meet
+    a_int = acc.compute_rdp(0.01, 1.0, 1, [3.0])[0]
+    a_lo, a_hi = acc.compute_rdp(0.01, 1.0, 1, [2.999])[0], acc.compute_rdp(0.01, 1.0, 1, [3.001])[0]
+    assert a_lo < a_int < a_hi and a_hi - a_lo < 1e-6
+    # composition and the sigma search
+    a = acc.RDPAccountant()
+    for _ in range(100):
+        a.step(noise_multiplier=1.0, sample_rate=0.01)
+    assert len(a) == 100 and a.history == [(1.0, 0.01, 100)]
+    e100 = a.get_epsilon(1e-5)
+    for _ in range(100):
+        a.step(noise_multiplier=1.0, sample_rate=0.01)
+    assert a.get_epsilon(1e-5) > e100 > 0
+    sigma = acc.get_noise_multiplier(target_epsilon=3.0, target_delta=1e-5, sample_rate=q, steps=steps)
+    got = acc.rdp_to_epsilon(acc.compute_rdp(q, sigma, steps), acc.DEFAULT_ALPHAS, 1e-5)[0]
+    assert got <= 3.0 and 3.0 - got < 0.02
+
+
+def test_module_validator_fix_and_poisson_loader():
+    import torch.nn as nn
+    from vqa_amd import dp
+    m = nn.Sequential(nn.Linear(8, 2048), nn.BatchNorm1d(2048), nn.ReLU(), nn.Linear(2048, 16),
+                      nn.BatchNorm1d(16))
+    assert not dp.ModuleValidator.is_valid(m)
+    m = dp.ModuleValidator.fix(m)
+    assert isinstance(m[1], nn.GroupNorm) and m[1].num_groups == 32 and m[1].num_channels == 2048
+    assert isinstance(m[4], nn.GroupNorm) and m[4].num_groups == 16   # min(32, n)
+    assert dp.ModuleValidator.is_valid(m)
+    assert not dp.ModuleValidator.is_valid(nn.Sequential(nn.Conv1d(3, 3, 1)))
+    ds = torch.utils.data.TensorDataset(torch.arange(1000.0))
+    dl = torch.utils.data.DataLoader(ds, batch_size=50)
+    pl = dp.DPDataLoader.from_data_loader(dl, generator=torch.Generator().manual_seed(0))
+    assert len(pl) == 20 and abs(pl.sample_rate - 0.05) < 1e-12
+    sizes = [0 if b is None else len(b[0]) for b in pl]
+    assert len(sizes) == 20 and 30 < sum(sizes) / 20 < 70 and len(set(sizes)) > 3  # Poisson, not fixed
+    with pytest.raises(ValueError):
+        dp.PrivacyEngine(secure_mode=True)
