@@ -169,6 +169,38 @@ int vqaf_gather_mix_pool_bwd(const void* grad_out, int ld_out, int col0, int g_d
                              const int64_t* idx, float alpha, int B, int N, int K, int D,
                              int dtype, void* grad_seq, vqaf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Dense single-query cross-attention (non-pruning branch): the attention OUTPUT of
+ * nn.MultiheadAttention(query=q[:,None], key=seq, value=seq), utils/fusion.py:257-268 and
+ * :173-179.  With one query per sample both projections fold out of the token loop:
+ *   s[b,n,h] = x_bn . u[b,h,:]   (vqaf_head_scores),   p[b,h,n] = softmax_n s[b,n,h],
+ *   z[b,h,:] = sum_n p[b,h,n] x_bn,   attn_h = Wv_h z_h + bv_h (sum_n p = 1),  out = out_proj(attn)
+ * and the backward re-uses the same two token passes plus one rank-2H update:
+ *   dp[b,n,h] = x_bn . t[b,h,:] (t_h = Wv_h^T d_attn_h),  ds = p * (dp - sum_n p dp),
+ *   du[b,h,:] = sum_n ds[b,h,n] x_bn,   grad_seq[b,n,:] = sum_h ds[b,h,n] u_h + p[b,h,n] t_h.
+ * The (B,H,D)-sized projections around these kernels are small GEMMs (vqaf_gemm_f32 or any BLAS).
+ * ------------------------------------------------------------------------------------ */
+
+/* u (B,H,D) f32 -> u_split (B,16,D) bf16 (see vqaf_fold_query); H <= 8. */
+int vqaf_split_u(const float* u, int B, int H, int D, void* u_split, vqaf_stream_t stream);
+
+/* p (B,H,N) f32 <- s (B,N,H) f32: softmax over n for every head. */
+int vqaf_softmax_heads(const float* s, int B, int N, int H, float* p, vqaf_stream_t stream);
+
+/* ds (B,H,N) <- p (B,H,N), dp (B,N,H): softmax backward per head. */
+int vqaf_softmax_heads_bwd(const float* p, const float* dp, int B, int N, int H, float* ds,
+                           vqaf_stream_t stream);
+
+/* z (B,H,D) f32 <- seq (B,N,D) `dtype`, c (B,H,N) f32:  z[b,h,:] = sum_n c[b,h,n] seq[b,n,:].
+ * Fixed summation order.  H <= 16 and H*N*4 + 8 KiB <= 64 KiB of LDS. */
+int vqaf_weighted_token_sum(const void* seq, const float* c, int B, int N, int D, int H, int dtype,
+                            float* z, vqaf_stream_t stream);
+
+/* out (B,N,D) `dtype` <- out[b,n,:] = sum_h ca[b,h,n] va[b,h,:] + cb[b,h,n] vb[b,h,:]
+ * (ca, cb (B,H,N) f32; va, vb (B,H,D) f32).  H <= 8 and 2*H*N*4 <= 64 KiB. */
+int vqaf_token_outer(const float* ca, const float* va, const float* cb, const float* vb, int B,
+                     int N, int D, int H, int dtype, void* out, vqaf_stream_t stream);
+
 /* Small strided-batched f32 GEMM used for the per-head projections around the kernels
  * above:  C[g][m][n] = alpha * sum_k A[g][m][k] * Bm[g][k][n] (+ bias[g][n]) (+ C if beta_one)
  * with element strides (s_g, s_m/s_k, s_k/s_n).  A and Bm may be f32 or bf16; C is f32. */

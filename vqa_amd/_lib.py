@@ -45,6 +45,11 @@ SIGNATURES = {
                                      c_int, c_int, _P, c_int, c_int, c_int, _P]),
     "vqaf_gather_mix_pool_bwd": (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_int, c_int, c_int,
                                          c_int, c_int, _P, _P]),
+    "vqaf_split_u": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "vqaf_softmax_heads": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "vqaf_softmax_heads_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    "vqaf_weighted_token_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vqaf_token_outer": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "vqaf_gemm_f32": (c_int, [_P, c_int, c_long, c_long, c_long, _P, c_int, c_long, c_long, c_long,
                               _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
                               c_float, c_int, _P]),

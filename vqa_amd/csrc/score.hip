@@ -267,6 +267,14 @@ static bool mfma_steps_ok(int D) {
   return D == 64 || D == 128 || D == 256 || D == 512 || D == 768 || D == 1024;
 }
 
+extern "C" int vqaf_split_u(const float* u, int B, int H, int D, void* u_split, vqaf_stream_t stream) {
+  VQAF_REQUIRE(u && u_split, VQAF_E_NULL);
+  VQAF_REQUIRE(B > 0 && D > 0 && H > 0 && H <= 8 && B <= 65535, VQAF_E_SHAPE);
+  hipLaunchKernelGGL(split_u_kernel, dim3((8 * D + SC_THREADS - 1) / SC_THREADS, B), dim3(SC_THREADS),
+                     0, (hipStream_t)stream, u, H, D, reinterpret_cast<bf16_t*>(u_split));
+  VQAF_LAUNCH_CHECK();
+}
+
 extern "C" int vqaf_head_scores(const void* seq, const float* u, const void* u_split, int B, int N,
                                 int D, int H, int dtype, float* s, vqaf_stream_t stream) {
   VQAF_REQUIRE(seq && u && s, VQAF_E_NULL);
