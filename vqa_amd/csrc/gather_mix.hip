@@ -6,12 +6,14 @@
 // 256/LPR rows in flight per step and every row is read from HBM exactly once by exactly one
 // workgroup.  Because a workgroup sees every token of its sample, the mix token (a sum over
 // the dropped rows) needs no cross-workgroup reduction and no atomics: the sum order is fixed.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 constexpr int GM_THREADS = 256;
-constexpr int GM_UNROLL = 4;
+constexpr int GM_UNROLL = 8;
 
 __device__ __forceinline__ void zero8(float (&v)[8]) {
 #pragma unroll
@@ -46,35 +48,32 @@ __device__ __forceinline__ void add_noise8(float (&v)[8], const float* noise, in
 
 // Shared-memory carve for the forward kernels.
 struct FwdSmem {
-  int* sidx;             // [K]  clamped index or -1
-  unsigned char* kept;   // [N]
-  unsigned short* drop;  // [N]  compacted list of dropped rows
-  float* red;            // [GM_THREADS * 8]
-  int* misc;             // [4]
+  int* sidx;   // [K]  clamped index or -1
+  int* pos;    // [N]  smallest j with idx[j] == n, GM_NONE if the row is dropped
+  float* red;  // [GM_THREADS * 8]
+  int* misc;   // [4]  {dropped rows, duplicate flag}
 };
+constexpr int GM_NONE = 0x7fffffff;
 __host__ __device__ inline size_t fwd_smem_bytes(int N, int K) {
-  size_t b = 0;
-  b += ((size_t)K * 4 + 15) & ~(size_t)15;
-  b += ((size_t)N + 15) & ~(size_t)15;
-  b += ((size_t)N * 2 + 15) & ~(size_t)15;
-  b += (size_t)GM_THREADS * 8 * 4;
-  b += 16;
-  return b;
+  return (((size_t)K * 4 + 15) & ~(size_t)15) + (((size_t)N * 4 + 15) & ~(size_t)15) +
+         (size_t)GM_THREADS * 8 * 4 + 16;
 }
 __device__ inline FwdSmem fwd_carve(unsigned char* base, int N, int K) {
   FwdSmem s;
   s.sidx = reinterpret_cast<int*>(base);
   base += ((size_t)K * 4 + 15) & ~(size_t)15;
-  s.kept = base;
-  base += ((size_t)N + 15) & ~(size_t)15;
-  s.drop = reinterpret_cast<unsigned short*>(base);
-  base += ((size_t)N * 2 + 15) & ~(size_t)15;
+  s.pos = reinterpret_cast<int*>(base);
+  base += ((size_t)N * 4 + 15) & ~(size_t)15;
   s.red = reinterpret_cast<float*>(base);
   base += (size_t)GM_THREADS * 8 * 4;
   s.misc = reinterpret_cast<int*>(base);
   return s;
 }
 
+// One streaming pass over the sample's rows in memory order: a kept row goes to its slot of the
+// output (or into the pooled sum), a dropped row into the mix-token sum.  Rows named more than
+// once in idx (never produced by the pruning module, allowed by torch.gather) are completed in a
+// short serial tail.
 // POOL == false: out is (B, Kout, D) with Kout = K + (alpha > 0).
 // POOL == true : out is (B, ld_out); writes columns [col0, col0 + D) with the token mean.
 template <bool BF16, bool BF16_OUT, int LPR, bool POOL>
@@ -85,6 +84,7 @@ gather_mix_kernel(const void* __restrict__ seq, const int64_t* __restrict__ idx,
                   void* __restrict__ out, int ld_out, int col0) {
   constexpr int ROWS = GM_THREADS / LPR;
   constexpr int SLW = 8 * LPR;
+  constexpr int U = 8;  // rows in flight per lane
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const FwdSmem sm = fwd_carve(smem_raw, N, K);
 
@@ -104,155 +104,179 @@ gather_mix_kernel(const void* __restrict__ seq, const int64_t* __restrict__ idx,
     counter = rng_state[1];
   }
 
-  // ---- index staging: sidx[j], kept[n] ----
-  for (int n = tid; n < N; n += GM_THREADS) sm.kept[n] = 0;
+  // Token rows are read in memory order, so the first batch of loads does not depend on the
+  // indices: it is issued before the index staging and lands while the staging runs.
+  const size_t seq_b = (size_t)b * N * D;
+  constexpr size_t esz = BF16 ? 2 : 4;
+  constexpr int W = BF16 ? 1 : 2;  // 16-byte pieces per lane and row
+  const unsigned char* row0 = reinterpret_cast<const unsigned char*>(seq) + (seq_b + d0) * esz;
+  u32x4 cur[U][W], nxt[U][W];
+  auto load_batch = [&](u32x4 (&dst)[U][W], int n0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = n0 + u * ROWS;
+#pragma unroll
+      for (int w = 0; w < W; ++w) dst[u][w] = u32x4{0u, 0u, 0u, 0u};
+      if (active && n < N) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(row0 + (size_t)n * D * esz);
+#pragma unroll
+        for (int w = 0; w < W; ++w) dst[u][w] = src[w];
+      }
+    }
+  };
+  load_batch(cur, g);
+
+  // ---- index staging: pos[n] = first j naming row n ----
+  for (int n = tid; n < N; n += GM_THREADS) sm.pos[n] = GM_NONE;
+  if (tid < 2) sm.misc[tid] = 0;
   __syncthreads();
   const int64_t* idx_b = idx + (size_t)b * K;
   for (int j = tid; j < K; j += GM_THREADS) {
     const int64_t n = idx_b[j];
     const bool ok = n >= 0 && n < (int64_t)N;
     sm.sidx[j] = ok ? (int)n : -1;
-    if (ok) sm.kept[n] = 1;
+    if (ok) atomicMin(&sm.pos[n], j);
   }
   __syncthreads();
-
-  // ---- wave 0: compact the dropped rows, ascending ----
-  if (with_mix && tid < VQAF_WAVE) {
-    int cnt = 0;
-    for (int base = 0; base < N; base += VQAF_WAVE) {
-      const int n = base + tid;
-      const bool dr = (n < N) && (sm.kept[n] == 0);
-      const unsigned long long m = __ballot(dr);
-      if (dr) sm.drop[cnt + __popcll(m & ((1ull << tid) - 1ull))] = (unsigned short)n;
-      cnt += __popcll(m);
+  {
+    int local = 0, odd = 0;
+    for (int n = tid; n < N; n += GM_THREADS) local += (sm.pos[n] == GM_NONE) ? 1 : 0;
+    for (int j = tid; j < K; j += GM_THREADS) {
+      const int n = sm.sidx[j];
+      if (n < 0 || sm.pos[n] != j) odd = 1;  // out-of-range or repeated index
     }
-    if (tid == 0) sm.misc[0] = cnt;
+    if (local) atomicAdd(&sm.misc[0], local);
+    if (odd) atomicOr(&sm.misc[1], 1);
   }
+  __syncthreads();
+  const int R = sm.misc[0];
+  const bool odd_idx = sm.misc[1] != 0;
 
-  const size_t seq_b = (size_t)b * N * D;
-  float acc[8];
-  zero8(acc);
+  float acck[8], accd[8];
+  zero8(acck);
+  zero8(accd);
+  const bool raw_copy = !POOL && BF16 == BF16_OUT && !has_noise;
 
-  // ---- gather phase ----
+  auto unpack = [&](const u32x4 (&r)[W], float (&v)[8]) {
+    if constexpr (BF16) {
+      v[0] = bf16_lo(r[0].x); v[1] = bf16_hi(r[0].x); v[2] = bf16_lo(r[0].y); v[3] = bf16_hi(r[0].y);
+      v[4] = bf16_lo(r[0].z); v[5] = bf16_hi(r[0].z); v[6] = bf16_lo(r[0].w); v[7] = bf16_hi(r[0].w);
+    } else {
+      v[0] = __uint_as_float(r[0].x); v[1] = __uint_as_float(r[0].y);
+      v[2] = __uint_as_float(r[0].z); v[3] = __uint_as_float(r[0].w);
+      v[4] = __uint_as_float(r[W - 1].x); v[5] = __uint_as_float(r[W - 1].y);
+      v[6] = __uint_as_float(r[W - 1].z); v[7] = __uint_as_float(r[W - 1].w);
+    }
+  };
+
   if (active) {
-    for (int j0 = g; j0 < K; j0 += GM_UNROLL * ROWS) {
-      if (!POOL && BF16 == BF16_OUT && !has_noise) {
-        // raw copy: bit-exact for every payload, NaNs included
-        constexpr int W = BF16 ? 1 : 2;  // 16-byte pieces per lane
-        u32x4 raw[GM_UNROLL][W];
+    for (int n0 = g; n0 < N; n0 += U * ROWS) {
+      const bool more = n0 + U * ROWS < N;
+      if (more) load_batch(nxt, n0 + U * ROWS);
 #pragma unroll
-        for (int u = 0; u < GM_UNROLL; ++u) {
-          const int j = j0 + u * ROWS;
-          const int n = (j < K) ? sm.sidx[j] : -1;
+      for (int u = 0; u < U; ++u) {
+        const int n = n0 + u * ROWS;
+        if (n < N) {
+          const int p = sm.pos[n];
+          float v[8];
+          if (p != GM_NONE) {
+            if (raw_copy) {
+              // kept rows are raw 16-byte copies: bit-exact for every payload, NaNs included
+              u32x4* dst = reinterpret_cast<u32x4*>(
+                  reinterpret_cast<unsigned char*>(out) + (((size_t)b * Kout + p) * D + d0) * esz);
 #pragma unroll
-          for (int w = 0; w < W; ++w) raw[u][w] = u32x4{0u, 0u, 0u, 0u};
-          if (n >= 0) {
-            const u32x4* src = reinterpret_cast<const u32x4*>(
-                reinterpret_cast<const unsigned char*>(seq) +
-                (seq_b + (size_t)n * D + d0) * (BF16 ? 2 : 4));
-#pragma unroll
-            for (int w = 0; w < W; ++w) raw[u][w] = src[w];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < GM_UNROLL; ++u) {
-          const int j = j0 + u * ROWS;
-          if (j < K) {
-            u32x4* dst = reinterpret_cast<u32x4*>(
-                reinterpret_cast<unsigned char*>(out) +
-                (((size_t)b * Kout + j) * D + d0) * (BF16 ? 2 : 4));
-#pragma unroll
-            for (int w = 0; w < W; ++w) dst[w] = raw[u][w];
-          }
-        }
-      } else {
-        float v[GM_UNROLL][8];
-#pragma unroll
-        for (int u = 0; u < GM_UNROLL; ++u) {
-          const int j = j0 + u * ROWS;
-          const int n = (j < K) ? sm.sidx[j] : -1;
-          zero8(v[u]);
-          if (n >= 0) load8<BF16>(seq, seq_b + (size_t)n * D + d0, v[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < GM_UNROLL; ++u) {
-          const int j = j0 + u * ROWS;
-          if (j < K) {
-            if (has_noise)
-              add_noise8(v[u], noise, noise_kind, noise_scale, seed, counter,
-                         ((size_t)b * K + j) * D + d0);
-            if constexpr (POOL) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) acc[i] += v[u][i];
+              for (int w = 0; w < W; ++w) dst[w] = cur[u][w];
             } else {
-              store8<BF16_OUT>(out, ((size_t)b * Kout + j) * D + d0, v[u]);
+              unpack(cur[u], v);
+              if (has_noise)
+                add_noise8(v, noise, noise_kind, noise_scale, seed, counter, ((size_t)b * K + p) * D + d0);
+              if constexpr (POOL) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acck[i] += v[i];
+              } else {
+                store8<BF16_OUT>(out, ((size_t)b * Kout + p) * D + d0, v);
+              }
             }
+          } else if (with_mix) {
+            unpack(cur[u], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) accd[i] += v[i];
           }
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int w = 0; w < W; ++w) cur[u][w] = nxt[u][w];
+      }
+    }
+    if (odd_idx) {
+      // slots whose index is out of range (zero row) or repeats an earlier one (same row again)
+      for (int j = g; j < K; j += ROWS) {
+        const int n = sm.sidx[j];
+        if (n >= 0 && sm.pos[n] == j) continue;
+        float v[8];
+        zero8(v);
+        if (n >= 0) {
+          load8<BF16>(seq, seq_b + (size_t)n * D + d0, v);
+          if (has_noise)
+            add_noise8(v, noise, noise_kind, noise_scale, seed, counter, ((size_t)b * K + j) * D + d0);
+        }
+        if constexpr (POOL) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acck[i] += v[i];
+        } else if (BF16 == BF16_OUT && !has_noise && n >= 0) {
+          const u32x4* src = reinterpret_cast<const u32x4*>(
+              reinterpret_cast<const unsigned char*>(seq) + (seq_b + (size_t)n * D + d0) * esz);
+          u32x4* dst = reinterpret_cast<u32x4*>(
+              reinterpret_cast<unsigned char*>(out) + (((size_t)b * Kout + j) * D + d0) * esz);
+          dst[0] = src[0];
+          if (!BF16) dst[1] = src[1];
+        } else {
+          store8<BF16_OUT>(out, ((size_t)b * Kout + j) * D + d0, v);
         }
       }
     }
   }
   if (!with_mix && !POOL) return;
-  __syncthreads();  // drop list + count visible
 
-  // ---- mix phase: fixed-order f32 sum over the dropped rows ----
-  float accd[8];
-  zero8(accd);
-  const int R = with_mix ? sm.misc[0] : 0;
-  if (active && with_mix) {
-    for (int r0 = g; r0 < R; r0 += GM_UNROLL * ROWS) {
-      float v[GM_UNROLL][8];
-#pragma unroll
-      for (int u = 0; u < GM_UNROLL; ++u) {
-        const int r = r0 + u * ROWS;
-        zero8(v[u]);
-        if (r < R) load8<BF16>(seq, seq_b + (size_t)sm.drop[r] * D + d0, v[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < GM_UNROLL; ++u)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) accd[i] += v[u][i];
-    }
-  }
+  // ---- fixed-order fold of the 256/LPR row groups ----
   // remaining_sum / (count + 1e-10), then * alpha  (same op order as the reference)
   const float cnt = (float)R + 1e-10f;
+  float sel[(SLW + GM_THREADS - 1) / GM_THREADS];
   if constexpr (POOL) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sm.red[tid * 8 + i] = acc[i];
-  } else {
+    for (int i = 0; i < 8; ++i) sm.red[tid * 8 + i] = acck[i];
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sm.red[tid * 8 + i] = accd[i];
-  }
-  __syncthreads();
-  if constexpr (POOL) {
-    // two reductions share the buffer: selected rows first, then dropped rows
-    float sel = 0.f;
-    const int c = tid;  // column within the slice
-    if (c < SLW) {
-      for (int gg = 0; gg < ROWS; ++gg) sel += sm.red[(gg * LPR + c / 8) * 8 + (c & 7)];
+    for (int q = 0; q < (SLW + GM_THREADS - 1) / GM_THREADS; ++q) {
+      const int c = tid + q * GM_THREADS;  // column within the slice
+      sel[q] = 0.f;
+      if (c < SLW)
+        for (int gg = 0; gg < ROWS; ++gg) sel[q] += sm.red[(gg * LPR + c / 8) * 8 + (c & 7)];
     }
     __syncthreads();
+  }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sm.red[tid * 8 + i] = accd[i];
-    __syncthreads();
+  for (int i = 0; i < 8; ++i) sm.red[tid * 8 + i] = accd[i];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < (SLW + GM_THREADS - 1) / GM_THREADS; ++q) {
+    const int c = tid + q * GM_THREADS;
     if (c < SLW) {
       float dr = 0.f;
       for (int gg = 0; gg < ROWS; ++gg) dr += sm.red[(gg * LPR + c / 8) * 8 + (c & 7)];
       const int d = blockIdx.x * SLW + c;
       if (d < D) {
-        float tot = sel;
-        if (with_mix) tot += alpha * (dr / cnt);
-        tot /= (float)Kout;
-        store1<BF16_OUT>(out, (size_t)b * ld_out + col0 + d, tot);
+        if constexpr (POOL) {
+          float tot = sel[q];
+          if (with_mix) tot += alpha * (dr / cnt);
+          store1<BF16_OUT>(out, (size_t)b * ld_out + col0 + d, tot / (float)Kout);
+        } else {
+          store1<BF16_OUT>(out, ((size_t)b * Kout + K) * D + d, alpha * (dr / cnt));
+        }
       }
-    }
-  } else {
-    const int c = tid;
-    if (c < SLW) {
-      float dr = 0.f;
-      for (int gg = 0; gg < ROWS; ++gg) dr += sm.red[(gg * LPR + c / 8) * 8 + (c & 7)];
-      const int d = blockIdx.x * SLW + c;
-      if (d < D) store1<BF16_OUT>(out, ((size_t)b * Kout + K) * D + d, alpha * (dr / cnt));
     }
   }
 }
@@ -287,6 +311,30 @@ gather_mix_bwd_kernel(const void* __restrict__ grad_out, int ld_out, int col0,
   const bool with_mix = alpha > 0.f;
   const int Kout = K + (with_mix ? 1 : 0);
   constexpr int NONE = POOL ? 0 : 0x7fffffff;
+  constexpr int U = 8;
+  constexpr int WG = BF16_G ? 1 : 2;  // 16-byte pieces per lane and grad_out row
+  constexpr size_t gsz = BF16_G ? 2 : 4;
+
+  // grad_out rows are read in memory order (j = 0, 1, ...), so the first batch does not depend
+  // on the indices and is issued before the index staging.
+  u32x4 cur[U][WG], nxt[U][WG];
+  const unsigned char* grow0 = nullptr;
+  if constexpr (!POOL)
+    grow0 = reinterpret_cast<const unsigned char*>(grad_out) + ((size_t)b * Kout * D + d0) * gsz;
+  auto load_batch = [&](u32x4 (&dst)[U][WG], int j0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * ROWS;
+#pragma unroll
+      for (int w = 0; w < WG; ++w) dst[u][w] = u32x4{0u, 0u, 0u, 0u};
+      if (active && j < K) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(grow0 + (size_t)j * D * gsz);
+#pragma unroll
+        for (int w = 0; w < WG; ++w) dst[u][w] = src[w];
+      }
+    }
+  };
+  if constexpr (!POOL) load_batch(cur, g);
 
   for (int n = tid; n < N; n += GM_THREADS) pos[n] = NONE;
   if (tid < 2) misc[tid] = 0;
@@ -338,31 +386,65 @@ gather_mix_bwd_kernel(const void* __restrict__ grad_out, int ld_out, int col0,
 #pragma unroll
       for (int i = 0; i < 8; ++i) gmix[i] = (alpha * t[i]) / cnt;
     }
-    for (int n0 = g; n0 < N; n0 += GM_UNROLL * ROWS) {
-      float v[GM_UNROLL][8];
+    if constexpr (POOL) {
+      for (int n0 = g; n0 < N; n0 += GM_UNROLL * ROWS) {
 #pragma unroll
-      for (int u = 0; u < GM_UNROLL; ++u) {
-        const int n = n0 + u * ROWS;
-        if (n < N) {
-          const int p = pos[n];
-          if constexpr (POOL) {
+        for (int u = 0; u < GM_UNROLL; ++u) {
+          const int n = n0 + u * ROWS;
+          if (n < N) {
+            const int p = pos[n];
+            float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[u][i] = (p == 0) ? gmix[i] : gsel[i] * (float)p;
-          } else {
-            if (p == NONE) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) v[u][i] = gmix[i];
-            } else {
-              load8<BF16_G>(grad_out, ((size_t)b * Kout + p) * D + d0, v[u]);
-            }
+            for (int i = 0; i < 8; ++i) v[i] = (p == 0) ? gmix[i] : gsel[i] * (float)p;
+            store8<BF16>(grad_seq, seq_b + (size_t)n * D + d0, v);
           }
         }
       }
+    } else {
+      // kept rows: grad_out row j goes to token row idx[j] (the first j naming a row wins here,
+      // later ones are added in the tail below)
+      for (int j0 = g; j0 < K; j0 += U * ROWS) {
+        const bool more = j0 + U * ROWS < K;
+        if (more) load_batch(nxt, j0 + U * ROWS);
 #pragma unroll
-      for (int u = 0; u < GM_UNROLL; ++u) {
-        const int n = n0 + u * ROWS;
-        if (n < N) store8<BF16>(grad_seq, seq_b + (size_t)n * D + d0, v[u]);
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + u * ROWS;
+          if (j < K) {
+            const int n = sidx[j];
+            if (n >= 0 && pos[n] == j) {
+              if constexpr (BF16_G == BF16) {
+                u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(grad_seq) +
+                                                      (seq_b + (size_t)n * D + d0) * gsz);
+#pragma unroll
+                for (int w = 0; w < WG; ++w) dst[w] = cur[u][w];
+              } else {
+                float v[8];
+                if constexpr (BF16_G) {
+                  v[0] = bf16_lo(cur[u][0].x); v[1] = bf16_hi(cur[u][0].x);
+                  v[2] = bf16_lo(cur[u][0].y); v[3] = bf16_hi(cur[u][0].y);
+                  v[4] = bf16_lo(cur[u][0].z); v[5] = bf16_hi(cur[u][0].z);
+                  v[6] = bf16_lo(cur[u][0].w); v[7] = bf16_hi(cur[u][0].w);
+                } else {
+                  v[0] = __uint_as_float(cur[u][0].x); v[1] = __uint_as_float(cur[u][0].y);
+                  v[2] = __uint_as_float(cur[u][0].z); v[3] = __uint_as_float(cur[u][0].w);
+                  v[4] = __uint_as_float(cur[u][WG - 1].x); v[5] = __uint_as_float(cur[u][WG - 1].y);
+                  v[6] = __uint_as_float(cur[u][WG - 1].z); v[7] = __uint_as_float(cur[u][WG - 1].w);
+                }
+                store8<BF16>(grad_seq, seq_b + (size_t)n * D + d0, v);
+              }
+            }
+          }
+        }
+        if (more) {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int w = 0; w < WG; ++w) cur[u][w] = nxt[u][w];
+        }
       }
+      // dropped rows: the broadcast mix gradient
+      for (int n = g; n < N; n += ROWS)
+        if (pos[n] == NONE) store8<BF16>(grad_seq, seq_b + (size_t)n * D + d0, gmix);
     }
   }
   if constexpr (!POOL) {
@@ -415,8 +497,7 @@ mean_pool_kernel(const void* __restrict__ x, int M, int D, void* __restrict__ ou
 #pragma unroll
   for (int i = 0; i < 8; ++i) red[tid * 8 + i] = acc[i];
   __syncthreads();
-  const int c = tid;
-  if (c < SLW) {
+  for (int c = tid; c < SLW; c += GM_THREADS) {
     float s = 0.f;
     for (int gg = 0; gg < ROWS; ++gg) s += red[(gg * LPR + c / 8) * 8 + (c & 7)];
     const int d = blockIdx.x * SLW + c;
@@ -442,8 +523,16 @@ mean_pool_bwd_kernel(const void* __restrict__ grad_out, int ld_out, int col0, in
 
 // Picks the slice width so that small batches still launch >= ~1024 workgroups.
 inline int pick_lpr(int B, int D) {
-  const int slices16 = (D + 127) / 128;
-  return ((long)B * slices16 >= 1024) ? 16 : 8;
+  static const int forced = [] {
+    const char* e = getenv("VQAF_GM_LPR");  // tuning knob: 8, 16, 32 or 64
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced;
+  // measured on MI355X (bf16, D = 512): 256-column slices once they still give >= 2048
+  // workgroups, 128-column slices down to 256 workgroups, 64-column slices for tiny batches
+  if ((long)B * ((D + 255) / 256) >= 2048) return 32;
+  if ((long)B * ((D + 127) / 128) >= 256) return 16;
+  return 8;
 }
 
 template <bool POOL>
@@ -458,17 +547,18 @@ int launch_fwd(const void* seq, const int64_t* idx, const float* noise, int nois
   hipLaunchKernelGGL((gather_mix_kernel<BF, BFO, L, POOL>), grid, block, smem, st, seq, idx,     \
                      noise, noise_kind, noise_scale, rng_state, alpha, N, K, D, out, ld_out, col0)
   const bool bf = dtype == VQAF_BF16, bfo = out_dtype == VQAF_BF16;
-  if (lpr == 16) {
-    if (bf && bfo) VQAF_GM_LAUNCH(true, true, 16);
-    else if (bf) VQAF_GM_LAUNCH(true, false, 16);
-    else if (!bfo) VQAF_GM_LAUNCH(false, false, 16);
-    else VQAF_GM_LAUNCH(false, true, 16);
-  } else {
-    if (bf && bfo) VQAF_GM_LAUNCH(true, true, 8);
-    else if (bf) VQAF_GM_LAUNCH(true, false, 8);
-    else if (!bfo) VQAF_GM_LAUNCH(false, false, 8);
-    else VQAF_GM_LAUNCH(false, true, 8);
-  }
+#define VQAF_GM_BY_DT(L)                                   \
+  do {                                                     \
+    if (bf && bfo) VQAF_GM_LAUNCH(true, true, L);          \
+    else if (bf) VQAF_GM_LAUNCH(true, false, L);           \
+    else if (!bfo) VQAF_GM_LAUNCH(false, false, L);        \
+    else VQAF_GM_LAUNCH(false, true, L);                   \
+  } while (0)
+  if (lpr == 64) VQAF_GM_BY_DT(64);
+  else if (lpr == 32) VQAF_GM_BY_DT(32);
+  else if (lpr == 16) VQAF_GM_BY_DT(16);
+  else VQAF_GM_BY_DT(8);
+#undef VQAF_GM_BY_DT
 #undef VQAF_GM_LAUNCH
   VQAF_LAUNCH_CHECK();
 }
@@ -484,17 +574,18 @@ int launch_bwd(const void* grad_out, int ld_out, int col0, int g_dtype, const in
   hipLaunchKernelGGL((gather_mix_bwd_kernel<BFG, BF, L, POOL>), grid, block, smem, st,       \
                      grad_out, ld_out, col0, idx, alpha, N, K, D, grad_seq)
   const bool bfg = g_dtype == VQAF_BF16, bf = dtype == VQAF_BF16;
-  if (lpr == 16) {
-    if (bfg && bf) VQAF_GMB_LAUNCH(true, true, 16);
-    else if (bfg) VQAF_GMB_LAUNCH(true, false, 16);
-    else if (bf) VQAF_GMB_LAUNCH(false, true, 16);
-    else VQAF_GMB_LAUNCH(false, false, 16);
-  } else {
-    if (bfg && bf) VQAF_GMB_LAUNCH(true, true, 8);
-    else if (bfg) VQAF_GMB_LAUNCH(true, false, 8);
-    else if (bf) VQAF_GMB_LAUNCH(false, true, 8);
-    else VQAF_GMB_LAUNCH(false, false, 8);
-  }
+#define VQAF_GMB_BY_DT(L)                                  \
+  do {                                                     \
+    if (bfg && bf) VQAF_GMB_LAUNCH(true, true, L);         \
+    else if (bfg) VQAF_GMB_LAUNCH(true, false, L);         \
+    else if (bf) VQAF_GMB_LAUNCH(false, true, L);          \
+    else VQAF_GMB_LAUNCH(false, false, L);                 \
+  } while (0)
+  if (lpr == 64) VQAF_GMB_BY_DT(64);
+  else if (lpr == 32) VQAF_GMB_BY_DT(32);
+  else if (lpr == 16) VQAF_GMB_BY_DT(16);
+  else VQAF_GMB_BY_DT(8);
+#undef VQAF_GMB_BY_DT
 #undef VQAF_GMB_LAUNCH
   VQAF_LAUNCH_CHECK();
 }
@@ -572,7 +663,7 @@ extern "C" int vqaf_mean_pool(const void* x, int B, int M, int D, int dtype, voi
   VQAF_REQUIRE(B > 0 && M > 0 && D > 0 && B <= 65535, VQAF_E_SHAPE);
   VQAF_REQUIRE(col0 >= 0 && ld_out >= col0 + D, VQAF_E_SHAPE);
   VQAF_REQUIRE(D % 8 == 0 && vqaf_aligned16(x), VQAF_E_ALIGN);
-  const int lpr = pick_lpr(B, D);
+  const int lpr = pick_lpr(B, D) > 16 ? 16 : pick_lpr(B, D);
   const dim3 grid((D + 8 * lpr - 1) / (8 * lpr), B), block(GM_THREADS);
   hipStream_t st = (hipStream_t)stream;
 #define VQAF_MP_LAUNCH(BF, BFO, L) \
@@ -600,7 +691,7 @@ extern "C" int vqaf_mean_pool_bwd(const void* grad_out, int ld_out, int col0, in
   VQAF_REQUIRE(B > 0 && M > 0 && D > 0 && B <= 65535, VQAF_E_SHAPE);
   VQAF_REQUIRE(col0 >= 0 && ld_out >= col0 + D, VQAF_E_SHAPE);
   VQAF_REQUIRE(D % 8 == 0 && vqaf_aligned16(grad_x), VQAF_E_ALIGN);
-  const int lpr = pick_lpr(B, D);
+  const int lpr = pick_lpr(B, D) > 16 ? 16 : pick_lpr(B, D);
   const dim3 grid((D + 8 * lpr - 1) / (8 * lpr), B), block(GM_THREADS);
   hipStream_t st = (hipStream_t)stream;
 #define VQAF_MPB_LAUNCH(BFG, BF, L)                                                            \

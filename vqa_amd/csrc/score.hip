@@ -11,6 +11,8 @@
 // wave-instruction) and the matching 8 x H slice of u in registers.  The H partial sums per
 // lane are combined with a halving exchange (4+2+1 shuffles for H = 8) followed by a 3-step
 // butterfly, instead of H full 6-step reductions.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -133,39 +135,61 @@ split_u_kernel(const float* __restrict__ u, int H, int D, bf16_t* __restrict__ u
 // 16-byte load straight from HBM: rows 64 B apart in k, so two consecutive steps use one 128-B
 // line), B = [bf16(u) | remainder] (32 columns x 16), so output column h holds x.u_hi and column
 // h+8 holds x.u_lo; their sum is the f32-accurate score.  No cross-lane reduction is needed.
+// The B operand (16 x D bf16 per sample) is staged once per workgroup in LDS (rows padded by
+// 16 B: conflict-free ds_read_b128) and shared by the four waves; token tiles are prefetched one
+// tile ahead, the first one before the LDS staging.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 template <int STEPS>
 __global__ void __launch_bounds__(SC_THREADS)
 head_scores_mfma_kernel(const bf16_t* __restrict__ seq, const bf16_t* __restrict__ us, int N, int H,
                         int tokb, float* __restrict__ s) {
   constexpr int D = 32 * STEPS;
+  constexpr int PITCH = D + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t ub[16 * PITCH];
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * tokb;
   const int t1 = min(N, t0 + tokb);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int col = lane & 15, kg = lane >> 4;
-  bf16x8_t bfr[STEPS];
-  {
-    const bf16_t* ub = us + ((size_t)b * 16 + col) * D + 8 * kg;
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st) bfr[st] = *reinterpret_cast<const bf16x8_t*>(ub + 32 * st);
-  }
-  for (int tile = t0 + 16 * wave; tile < t1; tile += 16 * SC_WAVES) {
+  const bf16_t* seq_b = seq + (size_t)b * N * D + 8 * kg;
+
+  bf16x8_t cur[STEPS], nxt[STEPS];
+  auto load_tile = [&](bf16x8_t (&dst)[STEPS], int tile) {
     const int row = min(tile + col, N - 1);  // rows past the end re-read the last token; never stored
-    const bf16_t* xr = seq + ((size_t)b * N + row) * D + 8 * kg;
-    bf16x8_t afr[STEPS];
+    const bf16_t* xr = seq_b + (size_t)row * D;
 #pragma unroll
-    for (int st = 0; st < STEPS; ++st) afr[st] = *reinterpret_cast<const bf16x8_t*>(xr + 32 * st);
+    for (int st = 0; st < STEPS; ++st) dst[st] = *reinterpret_cast<const bf16x8_t*>(xr + 32 * st);
+  };
+  int tile = t0 + 16 * wave;
+  if (tile < t1) load_tile(cur, tile);
+  {
+    const bf16_t* ug = us + (size_t)b * 16 * D;
+    for (int c = threadIdx.x; c < 16 * D / 8; c += SC_THREADS) {
+      const int r = c / (D / 8), k8 = c % (D / 8);
+      *reinterpret_cast<u32x4*>(&ub[r * PITCH + 8 * k8]) = *reinterpret_cast<const u32x4*>(ug + r * D + 8 * k8);
+    }
+  }
+  __syncthreads();
+  const bf16_t* ubl = &ub[col * PITCH + 8 * kg];
+  for (; tile < t1; tile += 16 * SC_WAVES) {
+    const bool more = tile + 16 * SC_WAVES < t1;
+    if (more) load_tile(nxt, tile + 16 * SC_WAVES);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int st = 0; st < STEPS; ++st)
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[st], bfr[st], acc, 0, 0, 0);
+    for (int st = 0; st < STEPS; ++st) {
+      const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(ubl + 32 * st);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[st], bf, acc, 0, 0, 0);
+    }
     // C/D layout: column = lane & 15, row = 4 * (lane >> 4) + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v = acc[r] + __shfl_xor(acc[r], 8, 64);
       const int tok = tile + 4 * kg + r;
       if (col < H && tok < t1) s[((size_t)b * N + tok) * H + col] = v;
+    }
+    if (more) {
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) cur[st] = nxt[st];
     }
   }
 }
@@ -283,7 +307,14 @@ extern "C" int vqaf_head_scores(const void* seq, const float* u, const void* u_s
   VQAF_REQUIRE(D % 8 == 0 && vqaf_aligned16(seq) && vqaf_aligned16(u), VQAF_E_ALIGN);
   if (dtype == VQAF_BF16 && u_split != nullptr && H <= 8 && mfma_steps_ok(D)) {
     VQAF_REQUIRE(vqaf_aligned16(u_split), VQAF_E_ALIGN);
-    const int tokb = ((long)B * ((N + 127) / 128) >= 2048) ? 128 : 64;
+    static const int forced_tokb = [] {
+      const char* e = getenv("VQAF_HS_TOKB");  // tuning knob: tokens per workgroup (multiple of 64)
+      return e ? atoi(e) : 0;
+    }();
+    int tokb = 64;
+    if ((long)B * ((N + 127) / 128) >= 512) tokb = 128;
+    if ((long)B * ((N + 255) / 256) >= 1024) tokb = 256;
+    if (forced_tokb >= 64 && forced_tokb % 64 == 0) tokb = forced_tokb;
     const dim3 grid((N + tokb - 1) / tokb, B), block(SC_THREADS);
     hipStream_t st = (hipStream_t)stream;
     const bf16_t* x = reinterpret_cast<const bf16_t*>(seq);
