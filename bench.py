@@ -282,6 +282,14 @@ def main():
         alg_bytes = local_b * (N_VIS * D * s + K * 8 + D * s)
         k_ms = probe.mean_ms()
         achieved = alg_bytes / k_ms / 1e6 if k_ms > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch from the PMC passes kept under profiles/ (same shape only)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            if local_b == 1024 and args.dtype == "bf16":
+                traffic = pmc["kernels"]["gather_mix_kernel<true, true, 32, true>"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         line = {
             "metric": "DP-SGD train samples/s (fusion+classifier+DP step, token-level inputs)",
             "value": round(args.batch * args.steps / dt, 1),
@@ -298,7 +306,7 @@ def main():
                        "global_batch": args.batch, "per_gpu_batch": local_b, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": "gather_mix_kernel<pool> (vision tokens)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(k_ms, 5), "algorithmic_bytes": alg_bytes},
         }
         if not args.no_sweep:

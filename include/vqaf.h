@@ -254,6 +254,20 @@ int vqaf_clipped_sum_affine(const void* xhat, const void* g, const float* coef, 
 int vqaf_noise_scale(const float* S, const float* noise, const uint64_t* rng_state,
                      float noise_std, float scale, size_t n, float* grad, vqaf_stream_t stream);
 
+/* vqaf_noise_scale followed by one AdamW update (torch.optim.AdamW semantics: decoupled weight
+ * decay, bias-corrected moments), fused over flat f32 buckets of n elements:
+ *   g = (S + noise_std z) * scale;  p *= 1 - lr*wd;  m += (1-b1)(g - m);  v = b2 v + (1-b2) g^2;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),   t = step[1] + 1.
+ * `step` = two uint64 in device memory {unused, updates applied so far} (advance it with
+ * vqaf_rng_advance after the call).  shadow_bf16 (n bf16, may be NULL) receives the updated
+ * parameters rounded to bf16; grad_out (n f32, may be NULL, may alias S) receives g.
+ * This is the step train.py:130-141 configures: AdamW on the classifier wrapped by the DP
+ * optimizer (utils/src.py:104). */
+int vqaf_dp_adamw(const float* S, const float* noise, const uint64_t* rng_state, float noise_std,
+                  float scale, float* param, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                  float* grad_out, size_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, const uint64_t* step, vqaf_stream_t stream);
+
 /* GroupNorm (+ optional ReLU) on (B,C) input, as the classifier holds after
  * ModuleValidator.fix swaps BatchNorm1d for GroupNorm(min(32,C), C) (train.py:124;
  * model/model.py:56-61).  Saves xhat (B,C) for the backward and the ghost norms. */

@@ -276,3 +276,49 @@ def test_ce_conf_shapes_dtypes_and_gradient(dev):
         lb = lg.bfloat16()
         loss_b, conf_b, _, _ = ops.ce_conf(lb.to(dev), y.to(dev))
         np.testing.assert_allclose(loss_b.cpu().numpy(), fo.per_sample_ce(lb.float(), y).numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_fused_adamw_step_matches_torch_adamw(dev):
+    """DPOptimizer's fused noise+scale+AdamW kernel against the unfused path
+    (vqaf_noise_scale followed by torch.optim.AdamW.step) over several steps, same injected noise."""
+    from vqa_amd import dp
+    in_dim, hidden, C, B = 128, 256, 100, 32
+    x, y = gi.normal(1, B, in_dim).to(dev), gi.labels(2, B, C).to(dev)
+
+    def make(fuse):
+        m = _classifier(77, in_dim, hidden, C).to(dev)
+        gsm = dp.GradSampleModule(m)
+        inner = torch.optim.AdamW(m.parameters(), lr=3e-3, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-7)
+        return gsm, dp.DPOptimizer(inner, gsm, noise_multiplier=0.7, max_grad_norm=1.0,
+                                   expected_batch_size=B, fuse_adamw=fuse)
+
+    gsm_f, opt_f = make(True)
+    gsm_u, opt_u = make(False)
+    assert opt_f._fusable() and not opt_u._fusable()
+    for step in range(4):
+        z = gi.normal(100 + step, opt_f._numel).to(dev)
+        for gsm, opt in ((gsm_f, opt_f), (gsm_u, opt_u)):
+            nn.CrossEntropyLoss()(gsm(x), y).backward()
+            opt.clip_and_accumulate()
+        opt_f._fused_step(noise=z)
+        opt_u.add_noise_and_scale(noise=z)
+        opt_u.original_optimizer.step()
+        for (n, pf), (_, pu) in zip(gsm_f.named_parameters(), gsm_u.named_parameters()):
+            np.testing.assert_allclose(pf.detach().cpu().numpy(), pu.detach().cpu().numpy(), rtol=2e-6, atol=1e-7,
+                                       err_msg=f"step {step} {n}")
+            gsc = float(pu.grad.abs().max())
+            np.testing.assert_allclose(pf.grad.cpu().numpy(), pu.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * gsc)
+    # the bf16 copy the next forward reads is the rounded parameter bucket
+    assert torch.equal(opt_f._shadow, opt_f._P.bfloat16())
+    assert gsm_f.shadow is not None and int(opt_f._step[1].item()) == 4
+    sd = opt_f.state_dict()
+    assert len(sd["state"]) == len(opt_f.params) and float(sd["state"][0]["step"]) == 4.0
+    ref_sd = opt_u.state_dict()
+    np.testing.assert_allclose(sd["state"][0]["exp_avg"].cpu().numpy(), ref_sd["state"][0]["exp_avg"].cpu().numpy(),
+                               rtol=1e-5, atol=1e-9)
+    # public step(): in-kernel noise, bf16 activations pick up the shadow weights
+    gsm_f.train()
+    nn.CrossEntropyLoss()(gsm_f(x.bfloat16()).float(), y).backward()
+    before = opt_f._P.clone()
+    opt_f.step()
+    assert not torch.equal(before, opt_f._P) and int(opt_f._step[1].item()) == 5

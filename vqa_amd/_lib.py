@@ -59,6 +59,8 @@ SIGNATURES = {
     "vqaf_clipped_sum_linear": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_clipped_sum_affine": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_noise_scale": (c_int, [_P, _P, _P, c_float, c_float, c_size_t, _P, _P]),
+    "vqaf_dp_adamw": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, c_float, c_float,
+                              c_float, c_float, c_float, _P, _P]),
     "vqaf_groupnorm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int, _P, _P,
                                    _P, _P]),
     "vqaf_groupnorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P,

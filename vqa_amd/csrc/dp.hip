@@ -404,6 +404,89 @@ noise_scale_kernel(const float* __restrict__ S, const float* __restrict__ noise,
   }
 }
 
+// Noise + scale + AdamW in one pass over the flat buckets (what DPOptimizer.step() does when it
+// wraps torch.optim.AdamW): g = (S + std z) * scale, then the decoupled-weight-decay Adam update
+// exactly as torch applies it (p *= 1 - lr wd; m, v moments; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)),
+// optionally refreshing a bf16 copy of the parameters for the next forward.  `step` holds the
+// number of updates already applied (device memory, so a replayed HIP graph keeps counting).
+__global__ void __launch_bounds__(DP_THREADS)
+dp_adamw_kernel(const float* __restrict__ S, const float* __restrict__ noise,
+                const uint64_t* __restrict__ rng_state, float noise_std, float scale,
+                float* __restrict__ param, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                bf16_t* __restrict__ shadow, float* __restrict__ grad_out, size_t n, float lr, float beta1,
+                float beta2, float eps, float weight_decay, const uint64_t* __restrict__ step) {
+  unsigned long long seed = 0, counter = 0;
+  const bool draw = (noise == nullptr) && (noise_std != 0.f);
+  if (draw) {
+    seed = rng_state[0];
+    counter = rng_state[1];
+  }
+  const float t = (float)(step[1] + 1ull);
+  const float bc1 = 1.f - powf(beta1, t);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, t));
+  const float step_size = lr / bc1;
+  const float decay = 1.f - lr * weight_decay;
+  const size_t ncall = (n + 3) >> 2;
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncall;
+       c += (size_t)gridDim.x * blockDim.x) {
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (draw) vqaf_normal4(seed, counter, c, z);
+    const size_t i0 = c << 2;
+    const int cnt = (i0 + 3 < n) ? 4 : (int)(n - i0);
+    float sv[4], pv[4], mv[4], vv[4];
+    if (cnt == 4) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(S + i0);
+      const f32x4 p4 = *reinterpret_cast<const f32x4*>(param + i0);
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(exp_avg + i0);
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(exp_avg_sq + i0);
+      sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w;
+      pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
+      mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+      vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+      if (noise != nullptr) {
+        const f32x4 n4 = *reinterpret_cast<const f32x4*>(noise + i0);
+        z[0] = n4.x; z[1] = n4.y; z[2] = n4.z; z[3] = n4.w;
+      }
+    } else {
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = j < cnt;
+        sv[j] = ok ? S[i0 + j] : 0.f;
+        pv[j] = ok ? param[i0 + j] : 0.f;
+        mv[j] = ok ? exp_avg[i0 + j] : 0.f;
+        vv[j] = ok ? exp_avg_sq[i0 + j] : 0.f;
+        if (noise != nullptr && ok) z[j] = noise[i0 + j];
+      }
+    }
+    float gv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = (sv[j] + noise_std * z[j]) * scale;
+      gv[j] = g;
+      pv[j] *= decay;
+      mv[j] = mv[j] + (1.f - beta1) * (g - mv[j]);           // lerp, as torch
+      vv[j] = beta2 * vv[j] + (1.f - beta2) * g * g;
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      pv[j] -= step_size * (mv[j] / denom);
+    }
+    if (cnt == 4) {
+      *reinterpret_cast<f32x4*>(param + i0) = f32x4{pv[0], pv[1], pv[2], pv[3]};
+      *reinterpret_cast<f32x4*>(exp_avg + i0) = f32x4{mv[0], mv[1], mv[2], mv[3]};
+      *reinterpret_cast<f32x4*>(exp_avg_sq + i0) = f32x4{vv[0], vv[1], vv[2], vv[3]};
+      if (grad_out != nullptr) *reinterpret_cast<f32x4*>(grad_out + i0) = f32x4{gv[0], gv[1], gv[2], gv[3]};
+      if (shadow != nullptr)
+        *reinterpret_cast<u32x2*>(shadow + i0) = u32x2{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+    } else {
+      for (int j = 0; j < cnt; ++j) {
+        param[i0 + j] = pv[j];
+        exp_avg[i0 + j] = mv[j];
+        exp_avg_sq[i0 + j] = vv[j];
+        if (grad_out != nullptr) grad_out[i0 + j] = gv[j];
+        if (shadow != nullptr) shadow[i0 + j] = f32_to_bf16(pv[j]);
+      }
+    }
+  }
+}
+
 // GroupNorm on (B,C): one workgroup per sample, a lane owns 8 consecutive channels, a group of
 // gs = C/groups channels spans gs/8 adjacent lanes (a power of two <= 64).
 template <bool BF16>
@@ -693,6 +776,29 @@ extern "C" int vqaf_noise_scale(const float* S, const float* noise, const uint64
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(noise_scale_kernel, dim3((unsigned)blocks), dim3(DP_THREADS), 0,
                      (hipStream_t)stream, S, noise, rng_state, noise_std, scale, n, grad);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_dp_adamw(const float* S, const float* noise, const uint64_t* rng_state,
+                             float noise_std, float scale, float* param, float* exp_avg,
+                             float* exp_avg_sq, void* shadow_bf16, float* grad_out, size_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay,
+                             const uint64_t* step, vqaf_stream_t stream) {
+  VQAF_REQUIRE(S && param && exp_avg && exp_avg_sq && step, VQAF_E_NULL);
+  VQAF_REQUIRE(n > 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(noise != nullptr || noise_std == 0.f || rng_state != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_aligned16(S) && vqaf_aligned16(param) && vqaf_aligned16(exp_avg) &&
+                   vqaf_aligned16(exp_avg_sq) && (noise == nullptr || vqaf_aligned16(noise)) &&
+                   (grad_out == nullptr || vqaf_aligned16(grad_out)) &&
+                   (shadow_bf16 == nullptr || (reinterpret_cast<uintptr_t>(shadow_bf16) & 7u) == 0),
+               VQAF_E_ALIGN);
+  const size_t ncall = (n + 3) / 4;
+  size_t blocks = (ncall + DP_THREADS - 1) / DP_THREADS;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dp_adamw_kernel, dim3((unsigned)blocks), dim3(DP_THREADS), 0, (hipStream_t)stream,
+                     S, noise, rng_state, noise_std, scale, param, exp_avg, exp_avg_sq,
+                     reinterpret_cast<bf16_t*>(shadow_bf16), grad_out, n, lr, beta1, beta2, eps,
+                     weight_decay, step);
   VQAF_LAUNCH_CHECK();
 }
 

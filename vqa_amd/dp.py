@@ -87,10 +87,22 @@ class ModuleValidator:
 class _Tape:
     """What one wrapped layer leaves behind for the optimizer step."""
 
-    __slots__ = ("module", "kind", "a", "g")
+    __slots__ = ("module", "kind", "a", "g", "shadow")
 
-    def __init__(self, module: nn.Module, kind: str):
-        self.module, self.kind, self.a, self.g = module, kind, None, None
+    def __init__(self, module: nn.Module, kind: str, shadow=None):
+        self.module, self.kind, self.a, self.g, self.shadow = module, kind, None, None, shadow
+
+
+def _as_dtype(p: torch.Tensor, dtype: torch.dtype, shadow) -> torch.Tensor:
+    """The parameter in the activation dtype: as is, from the optimizer's bf16 copy (kept current
+    by the fused step, so no cast kernel runs), or by a cast."""
+    if p.dtype == dtype:
+        return p
+    if shadow is not None and dtype == torch.bfloat16:
+        v = shadow.get(p.data_ptr())
+        if v is not None:
+            return v
+    return p.to(dtype)
 
 
 class _GhostLinear(torch.autograd.Function):
@@ -99,8 +111,8 @@ class _GhostLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, tape):
-        w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
-        b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
+        w = _as_dtype(weight, x.dtype, tape.shadow)
+        b = None if bias is None else _as_dtype(bias, x.dtype, tape.shadow)
         y = F.linear(x, w, b)
         ctx.save_for_backward(w)
         ctx.tape = tape
@@ -124,8 +136,8 @@ class _GhostGroupNorm(torch.autograd.Function):
     def forward(ctx, x, weight, bias, groups, eps, relu, tape):
         B, C = x.shape
         xc = x.contiguous()
-        ga = weight.detach().to(x.dtype).contiguous()
-        be = bias.detach().to(x.dtype).contiguous()
+        ga = _as_dtype(weight.detach(), x.dtype, tape.shadow).contiguous()
+        be = _as_dtype(bias.detach(), x.dtype, tape.shadow).contiguous()
         y = torch.empty_like(xc)
         xhat = torch.empty_like(xc)
         rstd = torch.empty(B, groups, dtype=torch.float32, device=x.device)
@@ -167,6 +179,7 @@ class GradSampleModule(nn.Module):
         self.loss_reduction = loss_reduction
         self.tapes: List[_Tape] = []
         self.last_batch_size = 0
+        self.shadow = None  # data_ptr of an f32 parameter -> its bf16 copy (set by DPOptimizer)
 
     def forward(self, x):
         self.tapes = []
@@ -190,7 +203,7 @@ class GradSampleModule(nn.Module):
         if isinstance(m, nn.Linear):
             if x.dim() != 2:
                 raise ValueError("per-sample rule implemented for Linear on (B, features) input")
-            tape = _Tape(m, "linear")
+            tape = _Tape(m, "linear", self.shadow)
             self.tapes.append(tape)
             return _GhostLinear.apply(x, m.weight, m.bias, tape)
         if isinstance(m, nn.GroupNorm):
@@ -202,7 +215,7 @@ class GradSampleModule(nn.Module):
     def _groupnorm(self, m: nn.GroupNorm, x, relu: bool):
         if x.dim() != 2 or not m.affine:
             raise ValueError("per-sample rule implemented for affine GroupNorm on (B, C) input")
-        tape = _Tape(m, "affine")
+        tape = _Tape(m, "affine", self.shadow)
         self.tapes.append(tape)
         return _GhostGroupNorm.apply(x, m.weight, m.bias, m.num_groups, m.eps, relu, tape)
 
@@ -215,8 +228,9 @@ class DPOptimizer:
 
     def __init__(self, optimizer: torch.optim.Optimizer, module: GradSampleModule, *,
                  noise_multiplier: float, max_grad_norm: float, expected_batch_size: int,
-                 seed: Optional[int] = None, process_group=None):
+                 seed: Optional[int] = None, process_group=None, fuse_adamw: bool = True):
         self.original_optimizer = optimizer
+        self.fuse_adamw = bool(fuse_adamw)
         self.module = module
         self.noise_multiplier = float(noise_multiplier)
         self.max_grad_norm = float(max_grad_norm)
@@ -234,6 +248,7 @@ class DPOptimizer:
         self._grad = None
         self._rng = None
         self._seed = seed
+        self._P = self._M = self._V = self._shadow = self._step = None
         self.last_norms = None
         self.last_clip = None
 
@@ -243,6 +258,13 @@ class DPOptimizer:
         return self.original_optimizer.param_groups
 
     def state_dict(self):
+        if self._step is not None:  # publish the fused step's moments in torch's own layout
+            t = float(self._step[1].item())
+            for p in self.params:
+                o = self._offsets[id(p)]
+                self.original_optimizer.state[p] = {
+                    "step": torch.tensor(t), "exp_avg": self._M[o:o + p.numel()].view_as(p),
+                    "exp_avg_sq": self._V[o:o + p.numel()].view_as(p)}
         return self.original_optimizer.state_dict()
 
     def load_state_dict(self, sd):
@@ -275,6 +297,68 @@ class DPOptimizer:
             seed = self._seed if self._seed is not None else torch.initial_seed()
             self._rng = ops.PhiloxState(device, seed=seed, stream_salt=1 + rank)
         return self._S, self._grad
+
+    def _fusable(self) -> bool:
+        """True when the wrapped optimizer is a plain torch AdamW over f32 parameters, whose update
+        the fused noise+scale+AdamW kernel reproduces exactly."""
+        opt = self.original_optimizer
+        if not self.fuse_adamw or type(opt) is not torch.optim.AdamW:
+            return False
+        if any(g.get("amsgrad") or g.get("maximize") or isinstance(g["lr"], torch.Tensor)
+               for g in opt.param_groups):
+            return False
+        return all(p.dtype == torch.float32 for p in self.params) and len(opt.state) == 0
+
+    def _fused_buffers(self, device):
+        """Flat parameter / moment buckets; every Parameter becomes a view of the flat bucket."""
+        if self._P is None:
+            self._P = torch.zeros(self._numel, dtype=torch.float32, device=device)
+            self._M = torch.zeros_like(self._P)
+            self._V = torch.zeros_like(self._P)
+            self._shadow = torch.zeros(self._numel, dtype=torch.bfloat16, device=device)
+            self._step = torch.zeros(2, dtype=torch.int64, device=device)
+            lookup = {}
+            with torch.no_grad():
+                for p in self.params:
+                    o = self._offsets[id(p)]
+                    view = self._P[o:o + p.numel()].view_as(p)
+                    view.copy_(p.data)
+                    p.data = view
+                    lookup[view.data_ptr()] = self._shadow[o:o + p.numel()].view_as(p)
+                self._shadow.copy_(self._P)
+            self.module.shadow = lookup
+
+    @torch.no_grad()
+    def _fused_step(self, noise: Optional[torch.Tensor] = None):
+        """(all-reduce) + noise + scale + AdamW + bf16 refresh in one pass per parameter group."""
+        import torch.distributed as dist
+        S, grad = self._S, self._grad
+        dev = S.device
+        self._fused_buffers(dev)
+        lib, st = load(), stream_ptr(dev)
+        world, _ = self._world()
+        std = self.noise_multiplier * self.max_grad_norm / math.sqrt(world)
+        scale = 1.0 / self.expected_batch_size
+        src = S
+        if world > 1:
+            self.add_noise_and_scale(noise)   # per-rank noise share, scale, sum all-reduce -> grad
+            src, std, scale, noise = grad, 0.0, 1.0, None
+        for group in self.original_optimizer.param_groups:
+            ps = [p for p in group["params"] if id(p) in self._offsets]
+            if not ps:
+                continue
+            lo = min(self._offsets[id(p)] for p in ps)
+            hi = max(self._offsets[id(p)] + (p.numel() + 3) // 4 * 4 for p in ps)
+            b1, b2 = group["betas"]
+            nz = noise[lo:hi] if noise is not None else None
+            check(lib.vqaf_dp_adamw(ptr(src[lo:hi]), ptr(nz), ptr(self._rng.state), std, scale,
+                                    ptr(self._P[lo:hi]), ptr(self._M[lo:hi]), ptr(self._V[lo:hi]),
+                                    ptr(self._shadow[lo:hi]), ptr(grad[lo:hi]), hi - lo, float(group["lr"]),
+                                    float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                    ptr(self._step), st), "vqaf_dp_adamw")
+            if world == 1 and nz is None and std != 0.0:
+                self._rng.advance()  # a fresh stream for the next group / step
+        check(lib.vqaf_rng_advance(ptr(self._step), 1, st), "vqaf_rng_advance")
 
     def _slice(self, buf, p):
         o = self._offsets[id(p)]
@@ -352,10 +436,18 @@ class DPOptimizer:
             self.accountant_hook(self)
 
     def step(self, closure=None):
-        self.pre_step()
+        if self._fusable() or self._P is not None:
+            self.clip_and_accumulate()
+            self._fused_step()
+            if self.accountant_hook is not None:
+                self.accountant_hook(self)
+            result = None
+        else:
+            self.pre_step()
+            result = self.original_optimizer.step()
         for t in self.module.tapes:  # a second step() without a new backward must fail loudly
             t.g = None
-        return self.original_optimizer.step()
+        return result
 
     def flat_noise_layout(self):
         """(name-less) list of (offset, numel, shape) per parameter in the flat buffers."""
