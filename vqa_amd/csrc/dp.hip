@@ -169,30 +169,37 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int kblock, int co
   return u.b;
 }
 
-// 8 consecutive bf16 of row `row` from column `col` (zeros outside the matrix).
+// 8 consecutive bf16 of row `row` from column `col`, as raw bits.  Loads are unconditional
+// (indices outside the matrix are clamped to a valid element) so that the loads of a stage issue
+// back to back; mask8() zeroes what was out of range when the registers are consumed.
 // VEC = elements per load instruction the row pitch allows: 8 (16 B), 2 (4 B) or 1.
 template <int VEC>
 __device__ __forceinline__ u32x4 load_row8(const bf16_t* base, int row, int nrows, int col, int ncols) {
-  u32x4 r = u32x4{0u, 0u, 0u, 0u};
-  if (row >= nrows) return r;
-  const bf16_t* p = base + (size_t)row * ncols + col;
+  const bf16_t* p = base + (size_t)min(row, nrows - 1) * ncols;
   if constexpr (VEC == 8) {
-    if (col < ncols) r = *reinterpret_cast<const u32x4*>(p);
+    return *reinterpret_cast<const u32x4*>(p + min(col, ncols - 8));
   } else if constexpr (VEC == 2) {
     const unsigned int* q = reinterpret_cast<const unsigned int*>(p);
-    unsigned int w[4] = {0u, 0u, 0u, 0u};
+    const int last = ncols / 2 - 1, c2 = col / 2;
+    return u32x4{q[min(c2, last)], q[min(c2 + 1, last)], q[min(c2 + 2, last)], q[min(c2 + 3, last)]};
+  } else {
+    unsigned int w[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (col + 2 * e < ncols) w[e] = q[e];
-    r = u32x4{w[0], w[1], w[2], w[3]};
-  } else {
-    unsigned int w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (col + e < ncols) w[e >> 1] |= ((unsigned int)p[e]) << ((e & 1) * 16);
-    r = u32x4{w[0], w[1], w[2], w[3]};
+      w[e] = (unsigned int)p[min(col + 2 * e, ncols - 1)] | ((unsigned int)p[min(col + 2 * e + 1, ncols - 1)] << 16);
+    return u32x4{w[0], w[1], w[2], w[3]};
   }
-  return r;
+}
+__device__ __forceinline__ u32x4 mask8(u32x4 v, int row, int nrows, int col, int ncols) {
+  const bool r = row < nrows;
+  unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned int lo = (r && col + 2 * e < ncols) ? 0xffffu : 0u;
+    const unsigned int hi = (r && col + 2 * e + 1 < ncols) ? 0xffff0000u : 0u;
+    w[e] &= (lo | hi);
+  }
+  return u32x4{w[0], w[1], w[2], w[3]};
 }
 
 __device__ __forceinline__ unsigned int scale_pack2(unsigned int w, float c, float& s0, float& s1) {
@@ -239,27 +246,28 @@ clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __res
     _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                \
       const int row = k0_ + gr + 16 * ps;                                             \
       rg[SET][ps] = load_row8<VEC_G>(g, row, B, m0 + gc, Out);                        \
-      rc[SET][ps] = row < B ? coef[row] : 0.f;                                        \
+      rc[SET][ps] = coef[min(row, B - 1)];                                            \
     }                                                                                 \
     ra[SET] = load_row8<VEC_A>(a, k0_ + ar, B, n0 + ac, In);                          \
   } while (0)
-#define CB_STASH(SET, BUF)                                                            \
+#define CB_STASH(SET, BUF, T)                                                         \
   do {                                                                                \
+    const int k0_ = (T) * CB_KB;                                                      \
     _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                \
       const float c = rc[SET][ps];                                                    \
-      u32x4 v = rg[SET][ps];                                                          \
+      u32x4 v = mask8(rg[SET][ps], k0_ + gr + 16 * ps, B, m0 + gc, Out);              \
       v.x = scale_pack2(v.x, c, bsum[0], bsum[1]);                                    \
       v.y = scale_pack2(v.y, c, bsum[2], bsum[3]);                                    \
       v.z = scale_pack2(v.z, c, bsum[4], bsum[5]);                                    \
       v.w = scale_pack2(v.w, c, bsum[6], bsum[7]);                                    \
       *reinterpret_cast<u32x4*>(&ldg[BUF][gr + 16 * ps][gc]) = v;                     \
     }                                                                                 \
-    *reinterpret_cast<u32x4*>(&lda[BUF][ar][ac]) = ra[SET];                           \
+    *reinterpret_cast<u32x4*>(&lda[BUF][ar][ac]) = mask8(ra[SET], k0_ + ar, B, n0 + ac, In); \
   } while (0)
 
   CB_FETCH(0, 0);
-  if (stages > 1) CB_FETCH(1, 1);
-  CB_STASH(0, 0);
+  CB_FETCH(1, 1);
+  CB_STASH(0, 0, 0);
   __syncthreads();
 #pragma unroll 1
   for (int s = 0; s < stages; s += 2) {
@@ -267,7 +275,10 @@ clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __res
     for (int P = 0; P < 2; ++P) {
       const int t = s + P;
       if (t < stages) {
-        if (t + 2 < stages) CB_FETCH(P, t + 2);  // set P is free: stage t already sits in LDS
+        // set P is free (stage t already sits in LDS).  The prefetch is unconditional -- past the
+        // last stage it re-reads clamped rows that nobody consumes -- because a conditional load
+        // would force the compiler to wait for ALL outstanding loads at the next use.
+        CB_FETCH(P, t + 2);
         const bf16_t* tg = &ldg[P][0][0];
         const bf16_t* ta = &lda[P][0][0];
 #pragma unroll
@@ -280,7 +291,7 @@ clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __res
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afv, bfv, acc[i], 0, 0, 0);
           }
         }
-        if (t + 1 < stages) CB_STASH(P ^ 1, P ^ 1);
+        if (t + 1 < stages) CB_STASH(P ^ 1, P ^ 1, t + 1);
         __syncthreads();
       }
     }

@@ -109,19 +109,17 @@ gather_mix_kernel(const void* __restrict__ seq, const int64_t* __restrict__ idx,
   const size_t seq_b = (size_t)b * N * D;
   constexpr size_t esz = BF16 ? 2 : 4;
   constexpr int W = BF16 ? 1 : 2;  // 16-byte pieces per lane and row
-  const unsigned char* row0 = reinterpret_cast<const unsigned char*>(seq) + (seq_b + d0) * esz;
+  // loads are unconditional (row / column clamped into the sample) so a batch issues back to back;
+  // rows past the end are simply never consumed
+  const unsigned char* row0 = reinterpret_cast<const unsigned char*>(seq) + (seq_b + min(d0, D - 8)) * esz;
   u32x4 cur[U][W], nxt[U][W];
   auto load_batch = [&](u32x4 (&dst)[U][W], int n0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int n = n0 + u * ROWS;
+      const int n = min(n0 + u * ROWS, N - 1);
+      const u32x4* src = reinterpret_cast<const u32x4*>(row0 + (size_t)n * D * esz);
 #pragma unroll
-      for (int w = 0; w < W; ++w) dst[u][w] = u32x4{0u, 0u, 0u, 0u};
-      if (active && n < N) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(row0 + (size_t)n * D * esz);
-#pragma unroll
-        for (int w = 0; w < W; ++w) dst[u][w] = src[w];
-      }
+      for (int w = 0; w < W; ++w) dst[u][w] = src[w];
     }
   };
   load_batch(cur, g);
@@ -172,7 +170,7 @@ gather_mix_kernel(const void* __restrict__ seq, const int64_t* __restrict__ idx,
   if (active) {
     for (int n0 = g; n0 < N; n0 += U * ROWS) {
       const bool more = n0 + U * ROWS < N;
-      if (more) load_batch(nxt, n0 + U * ROWS);
+      load_batch(nxt, n0 + U * ROWS);  // unconditional (clamped): keeps the waits counted
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int n = n0 + u * ROWS;
@@ -320,18 +318,14 @@ gather_mix_bwd_kernel(const void* __restrict__ grad_out, int ld_out, int col0,
   u32x4 cur[U][WG], nxt[U][WG];
   const unsigned char* grow0 = nullptr;
   if constexpr (!POOL)
-    grow0 = reinterpret_cast<const unsigned char*>(grad_out) + ((size_t)b * Kout * D + d0) * gsz;
-  auto load_batch = [&](u32x4 (&dst)[U][WG], int j0) {
+    grow0 = reinterpret_cast<const unsigned char*>(grad_out) + ((size_t)b * Kout * D + min(d0, D - 8)) * gsz;
+  auto load_batch = [&](u32x4 (&dst)[U][WG], int j0) {  // unconditional: rows clamped, extras unused
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int j = j0 + u * ROWS;
+      const int j = min(j0 + u * ROWS, K - 1);
+      const u32x4* src = reinterpret_cast<const u32x4*>(grow0 + (size_t)j * D * gsz);
 #pragma unroll
-      for (int w = 0; w < WG; ++w) dst[u][w] = u32x4{0u, 0u, 0u, 0u};
-      if (active && j < K) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(grow0 + (size_t)j * D * gsz);
-#pragma unroll
-        for (int w = 0; w < WG; ++w) dst[u][w] = src[w];
-      }
+      for (int w = 0; w < WG; ++w) dst[u][w] = src[w];
     }
   };
   if constexpr (!POOL) load_batch(cur, g);
@@ -405,7 +399,7 @@ gather_mix_bwd_kernel(const void* __restrict__ grad_out, int ld_out, int col0,
       // later ones are added in the tail below)
       for (int j0 = g; j0 < K; j0 += U * ROWS) {
         const bool more = j0 + U * ROWS < K;
-        if (more) load_batch(nxt, j0 + U * ROWS);
+        load_batch(nxt, j0 + U * ROWS);  // unconditional (clamped): keeps the waits counted
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int j = j0 + u * ROWS;
@@ -483,15 +477,14 @@ mean_pool_kernel(const void* __restrict__ x, int M, int D, void* __restrict__ ou
     for (int j0 = g; j0 < M; j0 += GM_UNROLL * ROWS) {
       float v[GM_UNROLL][8];
 #pragma unroll
+      for (int u = 0; u < GM_UNROLL; ++u)  // unconditional loads (row clamped), masked when added
+        load8<BF16>(x, ((size_t)b * M + min(j0 + u * ROWS, M - 1)) * D + d0, v[u]);
+#pragma unroll
       for (int u = 0; u < GM_UNROLL; ++u) {
-        const int j = j0 + u * ROWS;
-        zero8(v[u]);
-        if (j < M) load8<BF16>(x, ((size_t)b * M + j) * D + d0, v[u]);
+        const bool keep = j0 + u * ROWS < M;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += keep ? v[u][i] : 0.f;
       }
-#pragma unroll
-      for (int u = 0; u < GM_UNROLL; ++u)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += v[u][i];
     }
   }
 #pragma unroll

@@ -14,81 +14,97 @@ constexpr int GVECS = GT * GK / 4 / GTHREADS;  // 4-element groups per thread pe
 
 enum { G_KVEC = 0, G_XVEC = 1, G_SCALAR = 2 };  // contiguous along k / along m|n / neither
 
-__device__ __forceinline__ float ld1(const void* p, bool bf16, long off) {
-  return bf16 ? load1<true>(p, (size_t)off) : load1<false>(p, (size_t)off);
+// Raw (unconverted) loads: the conversion to f32 happens when the registers are written to LDS,
+// one or two stages later, so the compiler has no reason to wait for a load right after issuing it.
+template <bool BF16>
+__device__ __forceinline__ unsigned int ldraw1(const void* p, long off) {
+  if constexpr (BF16) return (unsigned int)reinterpret_cast<const bf16_t*>(p)[off];
+  else return reinterpret_cast<const unsigned int*>(p)[off];
 }
-// four consecutive elements starting at element offset `off` (a multiple of 4)
-__device__ __forceinline__ void ld4(const void* p, bool bf16, long off, float (&v)[4]) {
-  if (bf16) {
+template <bool BF16>
+__device__ __forceinline__ u32x4 ldraw4(const void* p, long off) {  // off: multiple of 4 elements
+  if constexpr (BF16) {
     const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p) + off);
+    return u32x4{r.x, r.y, 0u, 0u};
+  } else {
+    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(p) + off);
+  }
+}
+template <bool BF16, bool VEC>
+__device__ __forceinline__ void unpack4(const u32x4 r, float (&v)[4]) {
+  if constexpr (!BF16) {
+    v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+  } else if constexpr (VEC) {
     v[0] = bf16_lo(r.x); v[1] = bf16_hi(r.x); v[2] = bf16_lo(r.y); v[3] = bf16_hi(r.y);
   } else {
-    const f32x4 r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + off);
-    v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    v[0] = bf16_lo(r.x); v[1] = bf16_lo(r.y); v[2] = bf16_lo(r.z); v[3] = bf16_lo(r.w);
   }
 }
 
-// Loads this thread's share of a GT x GK operand tile.  x is the m (or n) index, k the
-// contraction index; element (x, k) lives at base + x*sx + k*sk.
 template <int MODE>
-__device__ __forceinline__ void fetch_tile(const void* p, bool bf16, long base, long sx, long sk,
-                                           int x0, int X, int k0, int K, int tid,
-                                           float (&r)[GVECS][4]) {
+__device__ __forceinline__ void tile_coords(int v, int& x, int& k) {
+  if (MODE == G_KVEC) { x = v / (GK / 4); k = (v % (GK / 4)) * 4; }
+  else if (MODE == G_XVEC) { x = (v % (GT / 4)) * 4; k = v / (GT / 4); }
+  else { x = v % GT; k = (v / GT) * 4; }
+}
+
+// Loads this thread's share of a GT x GK operand tile.  x is the m (or n) index, k the
+// contraction index; element (x, k) lives at base + x*sx + k*sk.  Every load is unconditional:
+// indices outside the matrix are clamped to a valid element (the value is zeroed when the tile is
+// written to LDS), so the loads of a stage issue back to back.  Vector modes are only selected
+// when the vectorised extent is a multiple of 4: a group is entirely inside or outside.
+template <int MODE, bool BF16>
+__device__ __forceinline__ void fetch_tile(const void* p, long base, long sx, long sk, int x0, int X,
+                                           int k0, int K, int tid, u32x4 (&r)[GVECS]) {
 #pragma unroll
   for (int i = 0; i < GVECS; ++i) {
-    const int v = tid + i * GTHREADS;
     int x, k;
-    if (MODE == G_KVEC) { x = v / (GK / 4); k = (v % (GK / 4)) * 4; }
-    else if (MODE == G_XVEC) { x = (v % (GT / 4)) * 4; k = v / (GT / 4); }
-    else { x = v % GT; k = (v / GT) * 4; }
+    tile_coords<MODE>(tid + i * GTHREADS, x, k);
     const int gx = x0 + x, gk = k0 + k;
     if (MODE == G_KVEC) {
-      if (gx < X && gk + 3 < K) ld4(p, bf16, base + gx * sx + gk, r[i]);
-      else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[i][e] = (gx < X && gk + e < K) ? ld1(p, bf16, base + gx * sx + gk + e) : 0.f;
-      }
+      r[i] = ldraw4<BF16>(p, base + (long)min(gx, X - 1) * sx + min(gk, K - 4));
     } else if (MODE == G_XVEC) {
-      if (gx + 3 < X && gk < K) ld4(p, bf16, base + gx + gk * sk, r[i]);
-      else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[i][e] = (gx + e < X && gk < K) ? ld1(p, bf16, base + gx + e + gk * sk) : 0.f;
-      }
+      r[i] = ldraw4<BF16>(p, base + min(gx, X - 4) + (long)min(gk, K - 1) * sk);
     } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        r[i][e] = (gx < X && gk + e < K) ? ld1(p, bf16, base + gx * sx + (gk + e) * sk) : 0.f;
+      const long rowb = base + (long)min(gx, X - 1) * sx;
+      r[i] = u32x4{ldraw1<BF16>(p, rowb + (long)min(gk, K - 1) * sk),
+                   ldraw1<BF16>(p, rowb + (long)min(gk + 1, K - 1) * sk),
+                   ldraw1<BF16>(p, rowb + (long)min(gk + 2, K - 1) * sk),
+                   ldraw1<BF16>(p, rowb + (long)min(gk + 3, K - 1) * sk)};
     }
   }
 }
-template <int MODE>
-__device__ __forceinline__ void store_tile(float (*T)[GP], int tid, const float (&r)[GVECS][4]) {
+// Converts, zeroes what lies outside the matrix and writes the tile k-major into LDS.
+template <int MODE, bool BF16>
+__device__ __forceinline__ void store_tile(float (*T)[GP], int tid, const u32x4 (&r)[GVECS], int x0,
+                                           int X, int k0, int K) {
 #pragma unroll
   for (int i = 0; i < GVECS; ++i) {
-    const int v = tid + i * GTHREADS;
+    int x, k;
+    tile_coords<MODE>(tid + i * GTHREADS, x, k);
+    const int gx = x0 + x, gk = k0 + k;
+    float v[4];
+    unpack4<BF16, MODE != G_SCALAR>(r[i], v);
     if (MODE == G_XVEC) {
-      const int x = (v % (GT / 4)) * 4, k = v / (GT / 4);
+      const bool ok = gx < X && gk < K;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) T[k][x + e] = r[i][e];
+      for (int e = 0; e < 4; ++e) T[k][x + e] = ok ? v[e] : 0.f;
     } else {
-      int x, k;
-      if (MODE == G_KVEC) { x = v / (GK / 4); k = (v % (GK / 4)) * 4; }
-      else { x = v % GT; k = (v / GT) * 4; }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) T[k + e][x] = r[i][e];
+      for (int e = 0; e < 4; ++e) T[k + e][x] = (gx < X && gk + e < K) ? v[e] : 0.f;
     }
   }
 }
 
 // Operands are staged k-major into LDS (As[k][m], Bs[k][n]) whatever their strides -- with
-// 16-byte (f32) / 8-byte (bf16) loads along whichever index is contiguous -- one stage ahead
+// 16-byte (f32) / 8-byte (bf16) loads along whichever index is contiguous -- two stages ahead
 // through registers, then each wave feeds v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fmaf
 // chain) one k pair at a time: lane l supplies A[m = l & 31][k = l >> 5] and
 // B[k = l >> 5][n = l & 31].
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, bool A_BF16, bool B_BF16>
 __global__ void __launch_bounds__(GTHREADS)
-gemm_f32_kernel(const void* __restrict__ A, int a_bf16, long a_sg, long a_sm, long a_sk,
-                const void* __restrict__ Bm, int b_bf16, long b_sg, long b_sk, long b_sn,
+gemm_f32_kernel(const void* __restrict__ A, long a_sg, long a_sm, long a_sk,
+                const void* __restrict__ Bm, long b_sg, long b_sk, long b_sn,
                 const void* __restrict__ bias, int bias_bf16, long bias_sg, float* __restrict__ C,
                 long c_sg, long c_sm, int M, int N, int K, float alpha, int beta_one) {
   __shared__ float As[2][GK][GP];
@@ -100,30 +116,40 @@ gemm_f32_kernel(const void* __restrict__ A, int a_bf16, long a_sg, long a_sm, lo
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   const long abase = (long)g * a_sg, bbase = (long)g * b_sg;
-  float ra[GVECS][4], rb[GVECS][4];
+  // register staging runs two stages ahead of the MFMAs (stage t lives in register set t & 1),
+  // LDS is double buffered: the loads of stage s+2 are in flight while stage s is multiplied
+  u32x4 ra[2][GVECS], rb[2][GVECS];
   const int stages = (K + GK - 1) / GK;
-  fetch_tile<AMODE>(A, a_bf16, abase, a_sm, a_sk, m0, M, 0, K, tid, ra);
-  fetch_tile<BMODE>(Bm, b_bf16, bbase, b_sn, b_sk, n0, N, 0, K, tid, rb);
-  store_tile<AMODE>(As[0], tid, ra);
-  store_tile<BMODE>(Bs[0], tid, rb);
+  fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, 0, K, tid, ra[0]);
+  fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, 0, K, tid, rb[0]);
+  fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, GK, K, tid, ra[1]);
+  fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, GK, K, tid, rb[1]);
+  store_tile<AMODE, A_BF16>(As[0], tid, ra[0], m0, M, 0, K);
+  store_tile<BMODE, B_BF16>(Bs[0], tid, rb[0], n0, N, 0, K);
   __syncthreads();
-  for (int s = 0; s < stages; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < stages) {
-      fetch_tile<AMODE>(A, a_bf16, abase, a_sm, a_sk, m0, M, (s + 1) * GK, K, tid, ra);
-      fetch_tile<BMODE>(Bm, b_bf16, bbase, b_sn, b_sk, n0, N, (s + 1) * GK, K, tid, rb);
-    }
+#pragma unroll 1
+  for (int s = 0; s < stages; s += 2) {
 #pragma unroll
-    for (int kk = 0; kk < GK; kk += 2) {
-      const float af = As[buf][kk + (lane >> 5)][wm * 32 + (lane & 31)];
-      const float bf = Bs[buf][kk + (lane >> 5)][wn * 32 + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+    for (int P = 0; P < 2; ++P) {
+      const int t = s + P;
+      if (t < stages) {
+        // set P is free (stage t already sits in LDS); the prefetch is unconditional (indices are
+        // clamped, surplus stages are never consumed) so that the waits below stay counted
+        fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, (t + 2) * GK, K, tid, ra[P]);
+        fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, (t + 2) * GK, K, tid, rb[P]);
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+          const float af = As[P][kk + (lane >> 5)][wm * 32 + (lane & 31)];
+          const float bf = Bs[P][kk + (lane >> 5)][wn * 32 + (lane & 31)];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+        }
+        if (t + 1 < stages) {
+          store_tile<AMODE, A_BF16>(As[P ^ 1], tid, ra[P ^ 1], m0, M, (t + 1) * GK, K);
+          store_tile<BMODE, B_BF16>(Bs[P ^ 1], tid, rb[P ^ 1], n0, N, (t + 1) * GK, K);
+        }
+        __syncthreads();
+      }
     }
-    if (s + 1 < stages) {
-      store_tile<AMODE>(As[buf ^ 1], tid, ra);
-      store_tile<BMODE>(Bs[buf ^ 1], tid, rb);
-    }
-    __syncthreads();
   }
   // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -132,7 +158,8 @@ gemm_f32_kernel(const void* __restrict__ A, int a_bf16, long a_sg, long a_sm, lo
     const int gn = n0 + wn * 32 + (lane & 31);
     if (gm < M && gn < N) {
       float v = alpha * acc[r];
-      if (bias != nullptr) v += ld1(bias, bias_bf16 != 0, (long)g * bias_sg + gn);
+      if (bias != nullptr)
+        v += bias_bf16 ? load1<true>(bias, (size_t)((long)g * bias_sg + gn)) : load1<false>(bias, (size_t)((long)g * bias_sg + gn));
       float* c = C + (long)g * c_sg + gm * c_sm + gn;
       if (beta_one) v += *c;
       *c = v;
@@ -141,11 +168,11 @@ gemm_f32_kernel(const void* __restrict__ A, int a_bf16, long a_sg, long a_sm, lo
 }
 
 // Vector loads need every 4-element group to start on an 8-byte (bf16) / 16-byte (f32) boundary.
-int pick_mode(const void* p, int dtype, long sg, long sx, long sk) {
+int pick_mode(const void* p, int dtype, long sg, long sx, long sk, int X, int K) {
   const size_t es = vqaf_esize(dtype);
   const bool base_ok = (reinterpret_cast<uintptr_t>(p) % (4 * es)) == 0 && sg % 4 == 0;
-  if (sk == 1 && base_ok && sx % 4 == 0) return G_KVEC;
-  if (sx == 1 && base_ok && sk % 4 == 0) return G_XVEC;
+  if (sk == 1 && base_ok && sx % 4 == 0 && K % 4 == 0) return G_KVEC;
+  if (sx == 1 && base_ok && sk % 4 == 0 && X % 4 == 0) return G_XVEC;
   return G_SCALAR;
 }
 
@@ -164,22 +191,30 @@ extern "C" int vqaf_gemm_f32(const void* A, int a_dtype, long a_sg, long a_sm, l
   VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);
   hipStream_t st = (hipStream_t)stream;
   const int bias_bf16 = bias_dtype == VQAF_BF16;
-  const int ab = a_dtype == VQAF_BF16, bb = b_dtype == VQAF_BF16;
-  const int am = pick_mode(A, a_dtype, a_sg, a_sm, a_sk), bm = pick_mode(Bm, b_dtype, b_sg, b_sn, b_sk);
-#define VQAF_GEMM_LAUNCH(AM, BM_)                                                                   \
-  hipLaunchKernelGGL((gemm_f32_kernel<AM, BM_>), grid, block, 0, st, A, ab, a_sg, a_sm, a_sk, Bm, bb, \
+  const bool ab = a_dtype == VQAF_BF16, bb = b_dtype == VQAF_BF16;
+  const int am = pick_mode(A, a_dtype, a_sg, a_sm, a_sk, M, K), bm = pick_mode(Bm, b_dtype, b_sg, b_sn, b_sk, N, K);
+#define VQAF_GEMM_LAUNCH(AM, BM_, AB, BB)                                                              \
+  hipLaunchKernelGGL((gemm_f32_kernel<AM, BM_, AB, BB>), grid, block, 0, st, A, a_sg, a_sm, a_sk, Bm,   \
                      b_sg, b_sk, b_sn, bias, bias_bf16, bias_sg, C, c_sg, c_sm, M, N, K, alpha, beta_one)
+#define VQAF_GEMM_BY_DT(AM, BM_)                            \
+  do {                                                      \
+    if (ab && bb) VQAF_GEMM_LAUNCH(AM, BM_, true, true);    \
+    else if (ab) VQAF_GEMM_LAUNCH(AM, BM_, true, false);    \
+    else if (bb) VQAF_GEMM_LAUNCH(AM, BM_, false, true);    \
+    else VQAF_GEMM_LAUNCH(AM, BM_, false, false);           \
+  } while (0)
   switch (am * 3 + bm) {
-    case 0: VQAF_GEMM_LAUNCH(G_KVEC, G_KVEC); break;
-    case 1: VQAF_GEMM_LAUNCH(G_KVEC, G_XVEC); break;
-    case 2: VQAF_GEMM_LAUNCH(G_KVEC, G_SCALAR); break;
-    case 3: VQAF_GEMM_LAUNCH(G_XVEC, G_KVEC); break;
-    case 4: VQAF_GEMM_LAUNCH(G_XVEC, G_XVEC); break;
-    case 5: VQAF_GEMM_LAUNCH(G_XVEC, G_SCALAR); break;
-    case 6: VQAF_GEMM_LAUNCH(G_SCALAR, G_KVEC); break;
-    case 7: VQAF_GEMM_LAUNCH(G_SCALAR, G_XVEC); break;
-    default: VQAF_GEMM_LAUNCH(G_SCALAR, G_SCALAR); break;
+    case 0: VQAF_GEMM_BY_DT(G_KVEC, G_KVEC); break;
+    case 1: VQAF_GEMM_BY_DT(G_KVEC, G_XVEC); break;
+    case 2: VQAF_GEMM_BY_DT(G_KVEC, G_SCALAR); break;
+    case 3: VQAF_GEMM_BY_DT(G_XVEC, G_KVEC); break;
+    case 4: VQAF_GEMM_BY_DT(G_XVEC, G_XVEC); break;
+    case 5: VQAF_GEMM_BY_DT(G_XVEC, G_SCALAR); break;
+    case 6: VQAF_GEMM_BY_DT(G_SCALAR, G_KVEC); break;
+    case 7: VQAF_GEMM_BY_DT(G_SCALAR, G_XVEC); break;
+    default: VQAF_GEMM_BY_DT(G_SCALAR, G_SCALAR); break;
   }
+#undef VQAF_GEMM_BY_DT
 #undef VQAF_GEMM_LAUNCH
   VQAF_LAUNCH_CHECK();
 }

@@ -161,7 +161,7 @@ head_scores_mfma_kernel(const bf16_t* __restrict__ seq, const bf16_t* __restrict
     for (int st = 0; st < STEPS; ++st) dst[st] = *reinterpret_cast<const bf16x8_t*>(xr + 32 * st);
   };
   int tile = t0 + 16 * wave;
-  if (tile < t1) load_tile(cur, tile);
+  load_tile(cur, tile);
   {
     const bf16_t* ug = us + (size_t)b * 16 * D;
     for (int c = threadIdx.x; c < 16 * D / 8; c += SC_THREADS) {
@@ -173,7 +173,7 @@ head_scores_mfma_kernel(const bf16_t* __restrict__ seq, const bf16_t* __restrict
   const bf16_t* ubl = &ub[col * PITCH + 8 * kg];
   for (; tile < t1; tile += 16 * SC_WAVES) {
     const bool more = tile + 16 * SC_WAVES < t1;
-    if (more) load_tile(nxt, tile + 16 * SC_WAVES);
+    load_tile(nxt, tile + 16 * SC_WAVES);  // unconditional (row clamped): keeps the waits counted
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
