@@ -443,3 +443,37 @@ def test_full_size_properties_bf16(dev, keep):
     # pooled variant agrees with the mean of the materialised tokens
     pooled = ops.pruned_pool([dict(seq=seq, idx=idx, alpha=0.05)], torch.float32)
     np.testing.assert_allclose(pooled.cpu().numpy(), out.float().mean(1).cpu().numpy(), rtol=BF16_RTOL, atol=2e-3)
+
+
+def test_fused_select_equals_separate_kernels(dev):
+    """vqaf_select (weights + ranking + swap in one launch) against the separate entry points:
+    same weights, same lists, and -- for the same RNG state -- the same adversarial draws."""
+    from vqa_amd import ops
+    from vqa_amd._lib import check, load, ptr, stream_ptr
+    for (B, N, H, K) in ((5, 197, 8, 98), (3, 577, 8, 288), (4, 30, 8, 15), (2, 1000, 4, 250), (3, 9, 1, 4)):
+        s = gi.normal(B + N, B, N, H, scale=1.5).to(dev)
+        w_sep = torch.empty(B, N, device=dev)
+        check(load().vqaf_attn_weights(ptr(s), B, N, H, ptr(w_sep), stream_ptr(dev)), "w")
+        top_sep, bot_sep = ops.topk_indices(w_sep, K)
+        k_adv = fo.adv_count(K, 0.2)
+        # no swap, from head scores and from weights
+        r = ops.select_indices(K, scores=s, want_weights=True, want_bottom=True)
+        np.testing.assert_allclose(r["weights"].cpu().numpy(), w_sep.cpu().numpy(), rtol=1e-6, atol=1e-9)
+        r2 = ops.select_indices(K, weights=w_sep, want_bottom=True)
+        assert torch.equal(r2["top"], top_sep) and torch.equal(r2["bottom"], bot_sep)
+        assert torch.equal(r["bottom"], bot_sep) or N > 500  # identical weights up to the last bit
+        if N - K < k_adv:
+            continue
+        # random swap: same state -> same draws as vqaf_adv_swap_random
+        rng_a, rng_b = ops.PhiloxState(dev, seed=5), ops.PhiloxState(dev, seed=5)
+        top_a = top_sep.clone()
+        pos_a, src_a = ops.adv_swap_random_(top_a, bot_sep, k_adv, rng_a, record=True)
+        r3 = ops.select_indices(K, weights=w_sep, k_adv=k_adv, rng=rng_b, want_bottom=True, record=True)
+        assert torch.equal(r3["pos"], pos_a) and torch.equal(r3["src"], src_a)
+        assert torch.equal(r3["top"], top_a) and torch.equal(r3["bottom"], bot_sep)
+        # injected swap
+        pos, src = gi.adversarial_draws(9, B, K, N - K, k_adv)
+        r4 = ops.select_indices(K, weights=w_sep, k_adv=k_adv, pos=pos.to(dev), src=src.to(dev))
+        top_b = top_sep.clone()
+        ops.adv_swap_(top_b, bot_sep, pos.to(dev), src.to(dev))
+        assert torch.equal(r4["top"], top_b)

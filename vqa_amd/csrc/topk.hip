@@ -109,6 +109,84 @@ __global__ void adv_swap_random_kernel(int64_t* __restrict__ top, const int64_t*
   }
 }
 
+// Whole keep-index selection of one sample in one workgroup: (optionally) head scores -> softmax
+// per head -> head mean, ranking, keep / bottom lists, adversarial swap with injected or in-kernel
+// draws.  Replaces four launches (weights, top-k, swap, counter bump is still separate) and keeps
+// the weights and both index lists in LDS in between.
+constexpr int SEL_MAX_H = 16;
+__global__ void select_kernel(const float* __restrict__ s, const float* __restrict__ w_in, int N, int H,
+                              int K, int NP, int adv_mode, int k_adv, int NPK, int NPR,
+                              const int64_t* __restrict__ pos, const int64_t* __restrict__ src,
+                              const uint64_t* __restrict__ rng_state, float* __restrict__ w_out,
+                              int64_t* __restrict__ top, int64_t* __restrict__ bottom,
+                              int64_t* __restrict__ pos_out, int64_t* __restrict__ src_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [NP]
+  int* rank = reinterpret_cast<int*>(keys + NP);                             // [N] full ranking
+  int* s_pos = rank + N;                                                     // [k_adv]
+  float* wl = reinterpret_cast<float*>(s_pos + (k_adv > 0 ? k_adv : 1));     // [N]
+  __shared__ float stat[2][SEL_MAX_H];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  const int R = N - K;
+
+  if (s != nullptr) {
+    const float* sb = s + (size_t)b * N * H;
+    for (int h = wave; h < H; h += nw) {  // a wave owns a head: no workgroup barrier inside
+      float m = -INFINITY;
+      for (int n = lane; n < N; n += 64) m = fmaxf(m, sb[(size_t)n * H + h]);
+      m = wave_max(m);
+      float z = 0.f;
+      for (int n = lane; n < N; n += 64) z += expf(sb[(size_t)n * H + h] - m);
+      z = wave_sum(z);
+      if (lane == 0) { stat[0][h] = m; stat[1][h] = z; }
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += nt) {
+      float a = 0.f;
+      for (int h = 0; h < H; ++h) a += expf(sb[(size_t)n * H + h] - stat[0][h]) / stat[1][h];
+      wl[n] = a / (float)H;
+    }
+  } else {
+    for (int n = tid; n < N; n += nt) wl[n] = w_in[(size_t)b * N + n];
+  }
+  __syncthreads();
+  if (w_out != nullptr)
+    for (int n = tid; n < N; n += nt) w_out[(size_t)b * N + n] = wl[n];
+  for (int i = tid; i < NP; i += nt)
+    keys[i] = (i < N) ? (((unsigned long long)order_key(wl[i]) << 32) |
+                         (unsigned long long)(0xffffffffu - (unsigned int)i))
+                      : 0ull;
+  __syncthreads();
+  bitonic_sort_desc(keys, NP);
+  for (int r = tid; r < N; r += nt) rank[r] = (int)(0xffffffffu - (unsigned int)keys[r]);
+  __syncthreads();
+  if (bottom != nullptr)  // the bottom list is reported before the swap, as the reference keeps it
+    for (int i = tid; i < R; i += nt) bottom[(size_t)b * R + i] = (int64_t)rank[N - 1 - i];
+
+  if (adv_mode == 1) {
+    for (int j = tid; j < k_adv; j += nt) {
+      const int64_t p = pos[(size_t)b * k_adv + j], q = src[(size_t)b * k_adv + j];
+      if (p >= 0 && p < K && q >= 0 && q < R) rank[p] = rank[N - 1 - (int)q];
+    }
+    __syncthreads();
+  } else if (adv_mode == 2) {
+    const unsigned long long seed = rng_state[0], counter = rng_state[1];
+    random_prefix(keys, K, NPK, seed, counter, 2ull * b);
+    for (int j = tid; j < k_adv; j += nt) s_pos[j] = TK_MAX_N - 1 - (int)(keys[j] & (TK_MAX_N - 1));
+    __syncthreads();
+    random_prefix(keys, R, NPR, seed, counter, 2ull * b + 1ull);
+    for (int j = tid; j < k_adv; j += nt) {
+      const int p = s_pos[j];
+      const int q = TK_MAX_N - 1 - (int)(keys[j] & (TK_MAX_N - 1));
+      rank[p] = rank[N - 1 - q];  // positions distinct, sources from the untouched tail: no hazard
+      if (pos_out != nullptr) pos_out[(size_t)b * k_adv + j] = p;
+      if (src_out != nullptr) src_out[(size_t)b * k_adv + j] = q;
+    }
+    __syncthreads();
+  }
+  for (int j = tid; j < K; j += nt) top[(size_t)b * K + j] = (int64_t)rank[j];
+}
+
 __global__ void rng_advance_kernel(uint64_t* state, uint64_t delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += delta;
 }
@@ -158,6 +236,31 @@ extern "C" int vqaf_adv_swap_random(int64_t* top, const int64_t* bottom, int B, 
   hipLaunchKernelGGL(adv_swap_random_kernel, dim3(B), dim3(sort_threads(NP)), (size_t)NP * 8,
                      (hipStream_t)stream, top, bottom, K, R, k_adv, NPK, NPR, rng_state, pos_out,
                      src_out);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_select(const float* s, const float* w_in, int B, int N, int H, int K, int adv_mode,
+                           int k_adv, const int64_t* pos, const int64_t* src,
+                           const uint64_t* rng_state, float* w_out, int64_t* top, int64_t* bottom,
+                           int64_t* pos_out, int64_t* src_out, vqaf_stream_t stream) {
+  VQAF_REQUIRE((s != nullptr) != (w_in != nullptr), VQAF_E_NULL);  // exactly one source of weights
+  VQAF_REQUIRE(top != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(B > 0 && N > 0 && K > 0 && K <= N && N <= TK_MAX_N, VQAF_E_SHAPE);
+  VQAF_REQUIRE(s == nullptr || (H > 0 && H <= SEL_MAX_H), VQAF_E_SHAPE);
+  VQAF_REQUIRE(adv_mode >= 0 && adv_mode <= 2, VQAF_E_SHAPE);
+  const int R = N - K;
+  if (adv_mode != 0) {
+    VQAF_REQUIRE(k_adv > 0 && k_adv <= K && k_adv <= R, VQAF_E_SHAPE);
+    if (adv_mode == 1) VQAF_REQUIRE(pos != nullptr && src != nullptr, VQAF_E_NULL);
+    if (adv_mode == 2) VQAF_REQUIRE(rng_state != nullptr, VQAF_E_NULL);
+  } else {
+    k_adv = 0;
+  }
+  const int NP = next_pow2(N), NPK = next_pow2(K), NPR = next_pow2(R > 0 ? R : 1);
+  const size_t smem = (size_t)NP * 8 + (size_t)N * 4 + (size_t)(k_adv > 0 ? k_adv : 1) * 4 + (size_t)N * 4;
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(sort_threads(NP)), smem, (hipStream_t)stream, s, w_in,
+                     N, H, K, NP, adv_mode, k_adv, NPK, NPR, pos, src, rng_state, w_out, top, bottom,
+                     pos_out, src_out);
   VQAF_LAUNCH_CHECK();
 }
 

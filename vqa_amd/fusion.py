@@ -46,28 +46,28 @@ class PrivacyAwareTokenPruning(nn.Module):
 
     # -- index selection: utils/fusion.py:35-65 ------------------------------------------------
     @torch.no_grad()
-    def select(self, attn_weights: torch.Tensor, n_tokens: int,
+    def select(self, attn_weights: Optional[torch.Tensor], n_tokens: int,
                replace_positions: Optional[torch.Tensor] = None,
-               random_bottom: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Keep indices (B,K) int64.  `replace_positions` / `random_bottom` (B,k_adv) inject the
-        draws of utils/fusion.py:59,62 (positions into the keep list / into the bottom list)."""
-        if attn_weights.dim() == 3:
-            attn_weights = attn_weights.squeeze(1)
+               random_bottom: Optional[torch.Tensor] = None,
+               head_scores: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Keep indices (B,K) int64, one kernel launch.  Give either `attn_weights` ((B,1,N) or
+        (B,N), the module-boundary form) or raw `head_scores` (B,N,H) whose softmax / head mean is
+        then fused into the same launch.  `replace_positions` / `random_bottom` (B,k_adv) inject
+        the draws of utils/fusion.py:59,62 (positions into the keep list / into the bottom list)."""
         k = ops.keep_count(n_tokens, self.prune_ratio)
         remaining_k = n_tokens - k
-        top, bottom = ops.topk_indices(attn_weights, k, need_bottom=bool(self.adversarial_mix))
+        k_adv = 0
         if self.adversarial_mix:
             k_adv = ops.adv_count(k, self.adv_ratio)
             # utils/fusion.py:57 -- the swap is skipped when fewer than k_adv tokens were dropped
-            if remaining_k >= k_adv:
-                if replace_positions is not None or random_bottom is not None:
-                    if replace_positions is None or random_bottom is None:
-                        raise ValueError("inject both replace_positions and random_bottom, or neither")
-                    ops.adv_swap_(top, bottom, replace_positions.to(torch.int64),
-                                  random_bottom.to(torch.int64))
-                else:
-                    ops.adv_swap_random_(top, bottom, k_adv, self.rng or ops.default_rng(top.device))
-        return top
+            if remaining_k < k_adv:
+                k_adv = 0
+        if (replace_positions is None) != (random_bottom is None):
+            raise ValueError("inject both replace_positions and random_bottom, or neither")
+        res = ops.select_indices(k, scores=head_scores, weights=attn_weights if head_scores is None else None,
+                                 k_adv=k_adv, pos=replace_positions if k_adv else None,
+                                 src=random_bottom if k_adv else None, rng=self.rng)
+        return res["top"]
 
     def _noise_args(self, noise: Optional[torch.Tensor]):
         if not self.noise_injection:
@@ -87,10 +87,11 @@ class PrivacyAwareTokenPruning(nn.Module):
         return ops.gather_mix(seq, idx, float(self.mixup_alpha), noise=noise_t, noise_type=noise_type,
                               noise_scale=float(self.noise_scale), rng=self.rng)
 
-    def pool_spec(self, seq, attn_weights, replace_positions=None, random_bottom=None, noise=None):
+    def pool_spec(self, seq, attn_weights, replace_positions=None, random_bottom=None, noise=None,
+                  head_scores=None):
         """Arguments for ops.pruned_pool: the same pruning, consumed as a token mean."""
         B, N, D = seq.shape
-        idx = self.select(attn_weights, N, replace_positions, random_bottom)
+        idx = self.select(attn_weights, N, replace_positions, random_bottom, head_scores=head_scores)
         self.last_indices = idx
         noise_t, noise_type = self._noise_args(noise)
         return dict(seq=seq, idx=idx, alpha=float(self.mixup_alpha), noise=noise_t,
@@ -109,7 +110,13 @@ class Concat(nn.Module):
 
 
 def _scores(mha: nn.MultiheadAttention, query: torch.Tensor, seq: torch.Tensor) -> torch.Tensor:
+    """Head-averaged attention weights (B,N): what the reference's MHA call returns."""
     return ops.attention_scores(query, seq, mha.in_proj_weight, mha.in_proj_bias, mha.num_heads)
+
+
+def _head_scores(mha: nn.MultiheadAttention, query: torch.Tensor, seq: torch.Tensor) -> torch.Tensor:
+    """Raw per-head scores (B,N,H); their softmax / head mean is fused into the selection kernel."""
+    return ops.head_score_matrix(query, seq, mha.in_proj_weight, mha.in_proj_bias, mha.num_heads)
 
 
 class Attention(nn.Module):
@@ -130,10 +137,12 @@ class Attention(nn.Module):
 
     def forward(self, v_seq, v_global, q_seq, q_global, **inject):
         if self.use_pruning:
-            w = _scores(self.attention, q_global, v_seq)
             if self.fuse_pool:
-                attended_v = ops.pruned_pool([self.pruning.pool_spec(v_seq, w, **inject)], v_seq.dtype)
+                hs = _head_scores(self.attention, q_global, v_seq)
+                attended_v = ops.pruned_pool([self.pruning.pool_spec(v_seq, None, head_scores=hs, **inject)],
+                                             v_seq.dtype)
             else:
+                w = _scores(self.attention, q_global, v_seq)
                 attended_v = ops.mean_pool(self.pruning(v_seq, w, **inject))
         else:
             from .xattn import single_query_attention
@@ -169,12 +178,13 @@ class CoAttention(nn.Module):
         v_inject = v_inject or {}
         q_inject = q_inject or {}
         if self.use_pruning:
-            v_w = _scores(self.txt_to_vis_attn, q_global, v_seq)      # utils/fusion.py:234-238
             if self.fuse_pool:
-                v_spec = self.v_pruning.pool_spec(v_seq, v_w, **v_inject)
-                q_w = _scores(self.vis_to_txt_attn, v_global, q_seq)  # utils/fusion.py:243-247
-                q_spec = self.q_pruning.pool_spec(q_seq, q_w, **q_inject)
-                return ops.pruned_pool([v_spec, q_spec], v_seq.dtype)  # :253-254, :274
+                v_hs = _head_scores(self.txt_to_vis_attn, q_global, v_seq)   # utils/fusion.py:234-238
+                v_spec = self.v_pruning.pool_spec(v_seq, None, head_scores=v_hs, **v_inject)
+                q_hs = _head_scores(self.vis_to_txt_attn, v_global, q_seq)   # utils/fusion.py:243-247
+                q_spec = self.q_pruning.pool_spec(q_seq, None, head_scores=q_hs, **q_inject)
+                return ops.pruned_pool([v_spec, q_spec], v_seq.dtype)        # :253-254, :274
+            v_w = _scores(self.txt_to_vis_attn, q_global, v_seq)
             v_pruned = self.v_pruning(v_seq, v_w, **v_inject)         # :240
             q_w = _scores(self.vis_to_txt_attn, v_global, q_seq)
             q_pruned = self.q_pruning(q_seq, q_w, **q_inject)         # :249

@@ -96,6 +96,76 @@ def attention_scores(q: torch.Tensor, seq: torch.Tensor, in_proj_weight: torch.T
 
 
 @torch.no_grad()
+def head_score_matrix(q: torch.Tensor, seq: torch.Tensor, in_proj_weight: torch.Tensor,
+                      in_proj_bias: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """Raw scaled per-head scores s (B,N,H) f32 (query fold + one pass over the tokens); the
+    softmax / head mean is left to `select_indices`, which fuses it with the ranking."""
+    B, N, D = seq.shape
+    H = num_heads
+    seq = seq.contiguous()
+    q = q.reshape(B, D).to(seq.dtype).contiguous()
+    w_ = in_proj_weight.detach().contiguous()
+    b_ = in_proj_bias.detach().to(w_.dtype).contiguous()
+    lib, st, dev = load(), stream_ptr(seq.device), seq.device
+    qp = torch.empty(B, D, dtype=torch.float32, device=dev)
+    u = torch.empty(B, H, D, dtype=torch.float32, device=dev)
+    split = None
+    if dtype_code(seq) == _lib.BF16 and H <= 8 and D in (64, 128, 256, 512, 768, 1024):
+        split = torch.empty(B, 16, D, dtype=torch.bfloat16, device=dev)
+    check(lib.vqaf_fold_query(ptr(q), ptr(w_), ptr(b_), B, D, H, dtype_code(seq), dtype_code(w_), ptr(qp),
+                              ptr(u), ptr(split), st), "vqaf_fold_query")
+    s = torch.empty(B, N, H, dtype=torch.float32, device=dev)
+    check(lib.vqaf_head_scores(ptr(seq), ptr(u), ptr(split), B, N, D, H, dtype_code(seq), ptr(s), st),
+          "vqaf_head_scores")
+    return s
+
+
+@torch.no_grad()
+def select_indices(k: int, *, scores: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None,
+                   k_adv: int = 0, pos: Optional[torch.Tensor] = None, src: Optional[torch.Tensor] = None,
+                   rng: Optional["PhiloxState"] = None, want_weights: bool = False,
+                   want_bottom: bool = False, record: bool = False) -> dict:
+    """Keep indices in one launch (vqaf_select): softmax/head-mean of `scores` (B,N,H) or given
+    `weights` (B,N), ranking, and the adversarial swap -- injected (`pos`, `src`), drawn in the
+    kernel (`rng`), or none (k_adv == 0)."""
+    if (scores is None) == (weights is None):
+        raise ValueError("pass exactly one of scores / weights")
+    if scores is not None:
+        scores = scores.contiguous()
+        B, N, H = scores.shape
+        dev = scores.device
+    else:
+        if weights.dim() == 3:
+            weights = weights.squeeze(1)
+        weights = weights.to(torch.float32).contiguous()
+        (B, N), H, dev = weights.shape, 0, weights.device
+    mode = 0
+    if k_adv > 0:
+        mode = 1 if pos is not None else 2
+        if mode == 1:
+            pos, src = pos.to(torch.int64).contiguous(), src.to(torch.int64).contiguous()
+        elif rng is None:
+            rng = default_rng(dev)
+    out = {"top": torch.empty(B, k, dtype=torch.int64, device=dev), "bottom": None, "weights": None,
+           "pos": None, "src": None}
+    if want_bottom and N > k:
+        out["bottom"] = torch.empty(B, N - k, dtype=torch.int64, device=dev)
+    if want_weights:
+        out["weights"] = torch.empty(B, N, dtype=torch.float32, device=dev)
+    if record and mode == 2:
+        out["pos"] = torch.empty(B, k_adv, dtype=torch.int64, device=dev)
+        out["src"] = torch.empty(B, k_adv, dtype=torch.int64, device=dev)
+    check(load().vqaf_select(ptr(scores), ptr(weights), B, N, H, k, mode, k_adv,
+                             ptr(pos) if mode == 1 else None, ptr(src) if mode == 1 else None,
+                             ptr(rng.state) if mode == 2 else None, ptr(out["weights"]), ptr(out["top"]),
+                             ptr(out["bottom"]), ptr(out["pos"]), ptr(out["src"]), stream_ptr(dev)),
+          "vqaf_select")
+    if mode == 2:
+        rng.advance()
+    return out
+
+
+@torch.no_grad()
 def topk_indices(w: torch.Tensor, k: int, need_bottom: bool = True
                  ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """(top (B,k) int64 weight-descending, bottom (B,N-k) int64 weight-ascending)."""
