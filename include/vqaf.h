@@ -63,24 +63,22 @@ const char* vqaf_status_string(int status);
  * ------------------------------------------------------------------------------------ */
 
 /* u (B,H,D) f32  <-  q (B,D) `dtype`, in_proj_weight (3D,D) / in_proj_bias (3D) `w_dtype`.
- * `qproj_ws` is a (B,D) f32 workspace.  If `u_split` is non-NULL (and H <= 8) it also receives
- * u as two bf16 terms, (B,16,D) bf16 with rows 0..7 = bf16(u_h) and rows 8..15 =
- * bf16(u_h - bf16(u_h)): the B operand of the bf16 matrix-core scoring kernel, whose sum
- * carries ~16 mantissa bits of u. */
+ * `qproj_ws` is a (B,D) f32 workspace. */
 int vqaf_fold_query(const void* q, const void* in_proj_weight, const void* in_proj_bias,
                     int B, int D, int H, int dtype, int w_dtype, float* qproj_ws, float* u,
-                    void* u_split, vqaf_stream_t stream);
+                    vqaf_stream_t stream);
 
 /* s (B,N,H) f32  <-  seq (B,N,D) `dtype`, u (B,H,D) f32.  Raw per-head scaled scores.
- * With bf16 tokens, H <= 8, D in {64,128,256,512,768,1024} and a non-NULL `u_split` the
- * products run on bf16 MFMA (tokens exact, u to ~2^-17); otherwise on the f32 vector ALU. */
-int vqaf_head_scores(const void* seq, const float* u, const void* u_split, int B, int N, int D,
-                     int H, int dtype, float* s, vqaf_stream_t stream);
+ * With bf16 tokens, H <= 8 and D in {64,128,256,512,768,1024} the products run on bf16 MFMA:
+ * tokens are exact, u enters as two bf16 terms bf16(u) + bf16(u - bf16(u)) (accurate to ~2^-17);
+ * otherwise on the f32 vector ALU. */
+int vqaf_head_scores(const void* seq, const float* u, int B, int N, int D, int H, int dtype,
+                     float* s, vqaf_stream_t stream);
 
 /* w (B,N) f32  <-  s (B,N,H) f32: softmax over n per head, then mean over heads. */
 int vqaf_attn_weights(const float* s, int B, int N, int H, float* w, vqaf_stream_t stream);
 
-/* Bytes of workspace vqaf_score needs (qproj + u + u_split + s), 256-byte aligned pieces. */
+/* Bytes of workspace vqaf_score needs (qproj + u + s), 256-byte aligned pieces. */
 size_t vqaf_score_workspace_bytes(int B, int N, int D, int H);
 
 /* The three steps above in one call: w (B,N) f32 <- q, seq, in_proj_{weight,bias}. */
@@ -191,9 +189,6 @@ int vqaf_gather_mix_pool_bwd(const void* grad_out, int ld_out, int col0, int g_d
  * The (B,H,D)-sized projections around these kernels are small GEMMs (vqaf_gemm_f32 or any BLAS).
  * ------------------------------------------------------------------------------------ */
 
-/* u (B,H,D) f32 -> u_split (B,16,D) bf16 (see vqaf_fold_query); H <= 8. */
-int vqaf_split_u(const float* u, int B, int H, int D, void* u_split, vqaf_stream_t stream);
-
 /* p (B,H,N) f32 <- s (B,N,H) f32: softmax over n for every head. */
 int vqaf_softmax_heads(const float* s, int B, int N, int H, float* p, vqaf_stream_t stream);
 
@@ -242,6 +237,16 @@ int vqaf_ghost_sqnorm_affine(const void* xhat, const void* g, int B, int C, int 
  * the raw backprops.  Opacus DPOptimizer.clip_and_accumulate. */
 int vqaf_clip_coef(const float* sq, int B, float max_norm, float scale, float* coef,
                    float* norms, vqaf_stream_t stream);
+
+/* The ghost norms of every wrapped layer and the clip coefficient in ONE launch (one workgroup
+ * per sample): same arithmetic as vqaf_ghost_sqnorm_linear / _affine accumulated over the layers
+ * followed by vqaf_clip_coef.  The *_host arguments are HOST arrays of n_layers entries (device
+ * pointers a[l], g[l]; in_dim / out_dim; kind 0 = Linear, 1 = Linear with bias, 2 = affine
+ * normalisation with a = xhat, in_dim ignored).  n_layers <= 8.  norms, sq (B) may be NULL. */
+int vqaf_ghost_clip(int n_layers, const void* const* a_host, const void* const* g_host,
+                    const int* in_dim_host, const int* out_dim_host, const int* kind_host, int B,
+                    int dtype, float max_norm, float scale, float* coef, float* norms, float* sq,
+                    vqaf_stream_t stream);
 
 /* Clipped gradient sum of a Linear:  SW (Out,In) f32 = sum_b coef[b] g_b a_b^T,
  * Sb (Out) f32 = sum_b coef[b] g_b (Sb may be NULL).  bf16 inputs use bf16 MFMA, f32

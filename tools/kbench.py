@@ -90,12 +90,10 @@ def main():
                                                 dtype_code(gseqs[0]), ptr(gseqs[i % nbuf]), st), "x"))
     # scoring
     u = torch.randn(B, H, D, device=dev)
-    us = torch.empty(B, 16, D, dtype=torch.bfloat16, device=dev)
-    check(lib.vqaf_split_u(ptr(u), B, H, D, ptr(us), st), "split")
     sc = torch.empty(B, N, H, device=dev)
     run("head_scores", B * (N * D * s + N * H * 4),
-        lambda i: check(lib.vqaf_head_scores(ptr(seqs[i % nbuf]), ptr(u), ptr(us) if a.dtype == "bf16" else None, B, N, D,
-                                             H, dtype_code(seqs[0]), ptr(sc), st), "x"))
+        lambda i: check(lib.vqaf_head_scores(ptr(seqs[i % nbuf]), ptr(u), B, N, D, H, dtype_code(seqs[0]), ptr(sc), st),
+                        "x"))
     wout = torch.empty(B, N, device=dev)
     run("attn_weights", B * (N * H * 4 + N * 4),
         lambda i: check(lib.vqaf_attn_weights(ptr(sc), B, N, H, ptr(wout), st), "x"))
@@ -113,7 +111,7 @@ def main():
     qp = torch.empty(B, D, device=dev)
     run("fold_query", 2 * D * D * s + B * D * s + B * H * D * 4,
         lambda i: check(lib.vqaf_fold_query(ptr(q), ptr(wq), ptr(bq), B, D, H, dtype_code(q), dtype_code(wq), ptr(qp), ptr(u),
-                                            ptr(us) if a.dtype == "bf16" else None, st), "x"))
+                                            st), "x"))
     # DP step kernels at the classifier's shapes
     for (In, Out) in ((1024, 2048), (2048, 1024), (1024, 430)):
         aa = torch.randn(B, In, device=dev).to(dt)

@@ -25,8 +25,8 @@ _P = c_void_p
 SIGNATURES = {
     "vqaf_version": (c_int, []),
     "vqaf_status_string": (c_char_p, [c_int]),
-    "vqaf_fold_query": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
-    "vqaf_head_scores": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vqaf_fold_query": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "vqaf_head_scores": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "vqaf_attn_weights": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "vqaf_score_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vqaf_score": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t,
@@ -46,7 +46,6 @@ SIGNATURES = {
                                      c_int, c_int, _P, c_int, c_int, c_int, _P]),
     "vqaf_gather_mix_pool_bwd": (c_int, [_P, c_int, c_int, c_int, _P, c_float, c_int, c_int, c_int,
                                          c_int, c_int, _P, _P]),
-    "vqaf_split_u": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "vqaf_softmax_heads": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "vqaf_softmax_heads_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "vqaf_weighted_token_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
@@ -57,6 +56,7 @@ SIGNATURES = {
     "vqaf_ghost_sqnorm_linear": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "vqaf_ghost_sqnorm_affine": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "vqaf_clip_coef": (c_int, [_P, c_int, c_float, c_float, _P, _P, _P]),
+    "vqaf_ghost_clip": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
     "vqaf_clipped_sum_linear": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_clipped_sum_affine": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_noise_scale": (c_int, [_P, _P, _P, c_float, c_float, c_size_t, _P, _P]),

@@ -64,6 +64,65 @@ ghost_sqnorm_affine_kernel(const void* __restrict__ xhat, const void* __restrict
   if (threadIdx.x == 0) sq[b] = accumulate ? sq[b] + s : s;
 }
 
+// All layers' ghost norms and the clip coefficient of one sample in one workgroup:
+//   sq = sum_layers { ||a||^2 ||g||^2 (+ ||g||^2 with a bias)   for a Linear
+//                   { sum (xhat g)^2 + sum g^2                   for an affine normalisation
+//   n = scale sqrt(sq);  coef = scale min(1, C / (n + 1e-6))
+constexpr int GC_MAX_LAYERS = 8;
+struct GhostLayers {
+  const void* a[GC_MAX_LAYERS];
+  const void* g[GC_MAX_LAYERS];
+  int in_dim[GC_MAX_LAYERS];
+  int out_dim[GC_MAX_LAYERS];
+  int kind[GC_MAX_LAYERS];  // 0 Linear without bias, 1 Linear with bias, 2 affine
+  int n;
+};
+template <bool BF16>
+__global__ void __launch_bounds__(DP_THREADS)
+ghost_clip_kernel(GhostLayers L, float max_norm, float scale, float* __restrict__ coef,
+                  float* __restrict__ norms, float* __restrict__ sq_out) {
+  __shared__ float red[DP_THREADS / 64];
+  const int b = blockIdx.x;
+  float total = 0.f;
+  for (int l = 0; l < L.n; ++l) {
+    const int In = L.in_dim[l], Out = L.out_dim[l];
+    if (L.kind[l] == 2) {
+      float s = 0.f;
+      for (int i = threadIdx.x * 8; i < Out; i += DP_THREADS * 8) {
+        float gv[8], xv[8];
+        load8<BF16>(L.g[l], (size_t)b * Out + i, gv);
+        load8<BF16>(L.a[l], (size_t)b * Out + i, xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xg = xv[e] * gv[e];
+          s = fmaf(xg, xg, s);
+          s = fmaf(gv[e], gv[e], s);
+        }
+      }
+      total += block_sum(s, red);
+    } else {
+      float na = 0.f, ng = 0.f;
+      for (int i = threadIdx.x; i < In; i += DP_THREADS) {
+        const float v = load1<BF16>(L.a[l], (size_t)b * In + i);
+        na = fmaf(v, v, na);
+      }
+      for (int i = threadIdx.x; i < Out; i += DP_THREADS) {
+        const float v = load1<BF16>(L.g[l], (size_t)b * Out + i);
+        ng = fmaf(v, v, ng);
+      }
+      na = block_sum(na, red);
+      ng = block_sum(ng, red);
+      total += na * ng + (L.kind[l] == 1 ? ng : 0.f);
+    }
+  }
+  if (threadIdx.x == 0) {
+    const float n = scale * sqrtf(total);
+    coef[b] = scale * fminf(1.0f, max_norm / (n + 1e-6f));
+    if (norms != nullptr) norms[b] = n;
+    if (sq_out != nullptr) sq_out[b] = total;
+  }
+}
+
 __global__ void clip_coef_kernel(const float* __restrict__ sq, int B, float max_norm, float scale,
                                  float* __restrict__ coef, float* __restrict__ norms) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -719,6 +778,37 @@ extern "C" int vqaf_clip_coef(const float* sq, int B, float max_norm, float scal
   VQAF_LAUNCH_CHECK();
 }
 
+extern "C" int vqaf_ghost_clip(int n_layers, const void* const* a_host, const void* const* g_host,
+                               const int* in_dim_host, const int* out_dim_host, const int* kind_host,
+                               int B, int dtype, float max_norm, float scale, float* coef, float* norms,
+                               float* sq, vqaf_stream_t stream) {
+  VQAF_REQUIRE(a_host && g_host && in_dim_host && out_dim_host && kind_host && coef, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(B > 0 && n_layers > 0 && n_layers <= GC_MAX_LAYERS, VQAF_E_SHAPE);
+  GhostLayers L;
+  L.n = n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    VQAF_REQUIRE(a_host[l] && g_host[l], VQAF_E_NULL);
+    VQAF_REQUIRE(in_dim_host[l] > 0 && out_dim_host[l] > 0 && kind_host[l] >= 0 && kind_host[l] <= 2,
+                 VQAF_E_SHAPE);
+    if (kind_host[l] == 2)
+      VQAF_REQUIRE(out_dim_host[l] % 8 == 0 && vqaf_aligned16(a_host[l]) && vqaf_aligned16(g_host[l]),
+                   VQAF_E_ALIGN);
+    L.a[l] = a_host[l];
+    L.g[l] = g_host[l];
+    L.in_dim[l] = in_dim_host[l];
+    L.out_dim[l] = out_dim_host[l];
+    L.kind[l] = kind_host[l];
+  }
+  if (dtype == VQAF_BF16)
+    hipLaunchKernelGGL(ghost_clip_kernel<true>, dim3(B), dim3(DP_THREADS), 0, (hipStream_t)stream, L,
+                       max_norm, scale, coef, norms, sq);
+  else
+    hipLaunchKernelGGL(ghost_clip_kernel<false>, dim3(B), dim3(DP_THREADS), 0, (hipStream_t)stream, L,
+                       max_norm, scale, coef, norms, sq);
+  VQAF_LAUNCH_CHECK();
+}
+
 extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float* coef, int B,
                                        int In, int Out, int dtype, int accumulate, float* SW,
                                        float* Sb, vqaf_stream_t stream) {
@@ -764,8 +854,12 @@ extern "C" int vqaf_clipped_sum_affine(const void* xhat, const void* g, const fl
   VQAF_REQUIRE(C % 8 == 0 && vqaf_aligned16(xhat) && vqaf_aligned16(g), VQAF_E_ALIGN);
   hipStream_t st = (hipStream_t)stream;
   if (!accumulate) {
-    if (Sgamma != nullptr && hipMemsetAsync(Sgamma, 0, (size_t)C * 4, st) != hipSuccess) return VQAF_E_LAUNCH;
-    if (Sbeta != nullptr && hipMemsetAsync(Sbeta, 0, (size_t)C * 4, st) != hipSuccess) return VQAF_E_LAUNCH;
+    if (Sgamma != nullptr && Sbeta == Sgamma + C) {  // adjacent slices of one flat bucket: one memset
+      if (hipMemsetAsync(Sgamma, 0, (size_t)2 * C * 4, st) != hipSuccess) return VQAF_E_LAUNCH;
+    } else {
+      if (Sgamma != nullptr && hipMemsetAsync(Sgamma, 0, (size_t)C * 4, st) != hipSuccess) return VQAF_E_LAUNCH;
+      if (Sbeta != nullptr && hipMemsetAsync(Sbeta, 0, (size_t)C * 4, st) != hipSuccess) return VQAF_E_LAUNCH;
+    }
   }
   const dim3 grid((C + 127) / 128, (B + AF_ROWS - 1) / AF_ROWS);
   VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);

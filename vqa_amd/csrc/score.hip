@@ -114,34 +114,18 @@ head_scores_kernel(const void* __restrict__ seq, const float* __restrict__ u, in
   }
 }
 
-// u (B,H,D) f32 -> us (B,16,D) bf16: rows 0..7 the bf16 rounding of u_h, rows 8..15 the bf16
-// rounding of the remainder (zero rows for h >= H).
-__global__ void __launch_bounds__(SC_THREADS)
-split_u_kernel(const float* __restrict__ u, int H, int D, bf16_t* __restrict__ us) {
-  const int b = blockIdx.y;
-  const int i = blockIdx.x * SC_THREADS + threadIdx.x;  // over 8 * D
-  if (i >= 8 * D) return;
-  const int h = i / D, d = i - h * D;
-  float v = 0.f;
-  if (h < H) v = u[((size_t)b * H + h) * D + d];
-  const bf16_t hi = f32_to_bf16(v);
-  const bf16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
-  us[((size_t)b * 16 + h) * D + d] = hi;
-  us[((size_t)b * 16 + 8 + h) * D + d] = lo;
-}
-
 // bf16 tokens on the matrix cores.  One wave scores 16 tokens per tile with
 // v_mfma_f32_16x16x32_bf16: A = the token tile (16 tokens x 32 columns per step, each lane one
 // 16-byte load straight from HBM: rows 64 B apart in k, so two consecutive steps use one 128-B
 // line), B = [bf16(u) | remainder] (32 columns x 16), so output column h holds x.u_hi and column
 // h+8 holds x.u_lo; their sum is the f32-accurate score.  No cross-lane reduction is needed.
-// The B operand (16 x D bf16 per sample) is staged once per workgroup in LDS (rows padded by
-// 16 B: conflict-free ds_read_b128) and shared by the four waves; token tiles are prefetched one
-// tile ahead, the first one before the LDS staging.
+// The B operand is built once per workgroup in LDS straight from u (f32): row h = bf16(u_h), row
+// h + 8 = bf16(u_h - bf16(u_h)) (rows padded by 16 B: conflict-free ds_read_b128), shared by the
+// four waves; token tiles are prefetched one tile ahead, the first one before the LDS staging.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 template <int STEPS>
 __global__ void __launch_bounds__(SC_THREADS)
-head_scores_mfma_kernel(const bf16_t* __restrict__ seq, const bf16_t* __restrict__ us, int N, int H,
+head_scores_mfma_kernel(const bf16_t* __restrict__ seq, const float* __restrict__ u, int N, int H,
                         int tokb, float* __restrict__ s) {
   constexpr int D = 32 * STEPS;
   constexpr int PITCH = D + 8;
@@ -163,10 +147,17 @@ head_scores_mfma_kernel(const bf16_t* __restrict__ seq, const bf16_t* __restrict
   int tile = t0 + 16 * wave;
   load_tile(cur, tile);
   {
-    const bf16_t* ug = us + (size_t)b * 16 * D;
-    for (int c = threadIdx.x; c < 16 * D / 8; c += SC_THREADS) {
-      const int r = c / (D / 8), k8 = c % (D / 8);
-      *reinterpret_cast<u32x4*>(&ub[r * PITCH + 8 * k8]) = *reinterpret_cast<const u32x4*>(ug + r * D + 8 * k8);
+    const float* ug = u + (size_t)b * H * D;
+    for (int c = threadIdx.x; c < 8 * D / 4; c += SC_THREADS) {
+      const int h = c / (D / 4), k4 = c % (D / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (h < H) v = *reinterpret_cast<const f32x4*>(ug + (size_t)h * D + 4 * k4);
+      const bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
+      const u32x2 hi = {(unsigned int)h0 | ((unsigned int)h1 << 16), (unsigned int)h2 | ((unsigned int)h3 << 16)};
+      const u32x2 lo = {pack_bf16x2(v.x - bf16_to_f32(h0), v.y - bf16_to_f32(h1)),
+                        pack_bf16x2(v.z - bf16_to_f32(h2), v.w - bf16_to_f32(h3))};
+      *reinterpret_cast<u32x2*>(&ub[h * PITCH + 4 * k4]) = hi;
+      *reinterpret_cast<u32x2*>(&ub[(h + 8) * PITCH + 4 * k4]) = lo;
     }
   }
   __syncthreads();
@@ -266,7 +257,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" int vqaf_fold_query(const void* q, const void* in_proj_weight, const void* in_proj_bias,
                                int B, int D, int H, int dtype, int w_dtype, float* qproj_ws,
-                               float* u, void* u_split, vqaf_stream_t stream) {
+                               float* u, vqaf_stream_t stream) {
   VQAF_REQUIRE(q && in_proj_weight && in_proj_bias && qproj_ws && u, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(w_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && D > 0 && H > 0 && D % H == 0, VQAF_E_SHAPE);
@@ -278,35 +269,21 @@ extern "C" int vqaf_fold_query(const void* q, const void* in_proj_weight, const 
   // u[b,h,:] = (1/sqrt(dh)) * qproj[b, h*dh:(h+1)*dh] @ Wk[h*dh:(h+1)*dh, :]
   const size_t esz = vqaf_esize(w_dtype);
   const void* wk = reinterpret_cast<const unsigned char*>(in_proj_weight) + (size_t)D * D * esz;
-  rc = vqaf_gemm_f32(qproj_ws, VQAF_F32, dh, D, 1, wk, w_dtype, (long)dh * D, D, 1, nullptr, 0, 0,
-                     u, D, (long)H * D, H, B, D, dh, 1.0f / sqrtf((float)dh), 0, stream);
-  if (rc != VQAF_OK || u_split == nullptr) return rc;
-  VQAF_REQUIRE(H <= 8 && B <= 65535, VQAF_E_SHAPE);
-  hipLaunchKernelGGL(split_u_kernel, dim3((8 * D + SC_THREADS - 1) / SC_THREADS, B), dim3(SC_THREADS),
-                     0, (hipStream_t)stream, u, H, D, reinterpret_cast<bf16_t*>(u_split));
-  VQAF_LAUNCH_CHECK();
+  return vqaf_gemm_f32(qproj_ws, VQAF_F32, dh, D, 1, wk, w_dtype, (long)dh * D, D, 1, nullptr, 0, 0,
+                       u, D, (long)H * D, H, B, D, dh, 1.0f / sqrtf((float)dh), 0, stream);
 }
 
 static bool mfma_steps_ok(int D) {
   return D == 64 || D == 128 || D == 256 || D == 512 || D == 768 || D == 1024;
 }
 
-extern "C" int vqaf_split_u(const float* u, int B, int H, int D, void* u_split, vqaf_stream_t stream) {
-  VQAF_REQUIRE(u && u_split, VQAF_E_NULL);
-  VQAF_REQUIRE(B > 0 && D > 0 && H > 0 && H <= 8 && B <= 65535, VQAF_E_SHAPE);
-  hipLaunchKernelGGL(split_u_kernel, dim3((8 * D + SC_THREADS - 1) / SC_THREADS, B), dim3(SC_THREADS),
-                     0, (hipStream_t)stream, u, H, D, reinterpret_cast<bf16_t*>(u_split));
-  VQAF_LAUNCH_CHECK();
-}
-
-extern "C" int vqaf_head_scores(const void* seq, const float* u, const void* u_split, int B, int N,
-                                int D, int H, int dtype, float* s, vqaf_stream_t stream) {
+extern "C" int vqaf_head_scores(const void* seq, const float* u, int B, int N, int D, int H,
+                                int dtype, float* s, vqaf_stream_t stream) {
   VQAF_REQUIRE(seq && u && s, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && N > 0 && D > 0 && H > 0 && B <= 65535, VQAF_E_SHAPE);
   VQAF_REQUIRE(D % 8 == 0 && vqaf_aligned16(seq) && vqaf_aligned16(u), VQAF_E_ALIGN);
-  if (dtype == VQAF_BF16 && u_split != nullptr && H <= 8 && mfma_steps_ok(D)) {
-    VQAF_REQUIRE(vqaf_aligned16(u_split), VQAF_E_ALIGN);
+  if (dtype == VQAF_BF16 && H <= 8 && mfma_steps_ok(D)) {
     static const int forced_tokb = [] {
       const char* e = getenv("VQAF_HS_TOKB");  // tuning knob: tokens per workgroup (multiple of 64)
       return e ? atoi(e) : 0;
@@ -318,8 +295,7 @@ extern "C" int vqaf_head_scores(const void* seq, const float* u, const void* u_s
     const dim3 grid((N + tokb - 1) / tokb, B), block(SC_THREADS);
     hipStream_t st = (hipStream_t)stream;
     const bf16_t* x = reinterpret_cast<const bf16_t*>(seq);
-    const bf16_t* us = reinterpret_cast<const bf16_t*>(u_split);
-#define VQAF_HSM(S) hipLaunchKernelGGL(head_scores_mfma_kernel<S>, grid, block, 0, st, x, us, N, H, tokb, s)
+#define VQAF_HSM(S) hipLaunchKernelGGL(head_scores_mfma_kernel<S>, grid, block, 0, st, x, u, N, H, tokb, s)
     switch (D / 32) {
       case 2: VQAF_HSM(2); break;
       case 4: VQAF_HSM(4); break;
@@ -387,7 +363,7 @@ extern "C" int vqaf_attn_weights(const float* s, int B, int N, int H, float* w,
 extern "C" size_t vqaf_score_workspace_bytes(int B, int N, int D, int H) {
   if (B <= 0 || N <= 0 || D <= 0 || H <= 0) return 0;
   return align256((size_t)B * D * 4) + align256((size_t)B * H * D * 4) +
-         align256((size_t)B * 16 * D * 2) + align256((size_t)B * N * H * 4);
+         align256((size_t)B * N * H * 4);
 }
 
 extern "C" int vqaf_score(const void* q, const void* seq, const void* in_proj_weight,
@@ -401,14 +377,10 @@ extern "C" int vqaf_score(const void* q, const void* seq, const void* in_proj_we
   unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
   float* qproj = reinterpret_cast<float*>(ws);
   float* u = reinterpret_cast<float*>(ws + align256((size_t)B * D * 4));
-  void* us = ws + align256((size_t)B * D * 4) + align256((size_t)B * H * D * 4);
-  float* s = reinterpret_cast<float*>(ws + align256((size_t)B * D * 4) + align256((size_t)B * H * D * 4) +
-                                      align256((size_t)B * 16 * D * 2));
-  const bool split = dtype == VQAF_BF16 && H <= 8 && mfma_steps_ok(D);
-  int rc = vqaf_fold_query(q, in_proj_weight, in_proj_bias, B, D, H, dtype, w_dtype, qproj, u,
-                           split ? us : nullptr, stream);
+  float* s = reinterpret_cast<float*>(ws + align256((size_t)B * D * 4) + align256((size_t)B * H * D * 4));
+  int rc = vqaf_fold_query(q, in_proj_weight, in_proj_bias, B, D, H, dtype, w_dtype, qproj, u, stream);
   if (rc != VQAF_OK) return rc;
-  rc = vqaf_head_scores(seq, u, split ? us : nullptr, B, N, D, H, dtype, s, stream);
+  rc = vqaf_head_scores(seq, u, B, N, D, H, dtype, s, stream);
   if (rc != VQAF_OK) return rc;
   return vqaf_attn_weights(s, B, N, H, w, stream);
 }

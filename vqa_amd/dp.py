@@ -375,25 +375,40 @@ class DPOptimizer:
         S, _ = self._buffers(dev)
         B = tapes[0].g.shape[0]
         st = stream_ptr(dev)
-        sq = torch.empty(B, dtype=torch.float32, device=dev)
-        for i, t in enumerate(tapes):
+        for t in tapes:
             a, g = t.a.contiguous(), t.g.contiguous()
-            if a.dtype != g.dtype:
-                a = a.to(g.dtype)
-                t.a = a
-            if t.kind == "linear":
-                check(lib.vqaf_ghost_sqnorm_linear(ptr(a), ptr(g), B, a.shape[1], g.shape[1],
-                                                   dtype_code(g), int(t.module.bias is not None),
-                                                   int(i > 0), ptr(sq), st), "vqaf_ghost_sqnorm_linear")
-            else:
-                check(lib.vqaf_ghost_sqnorm_affine(ptr(a), ptr(g), B, g.shape[1], dtype_code(g),
-                                                   int(i > 0), ptr(sq), st), "vqaf_ghost_sqnorm_affine")
+            t.a = a if a.dtype == g.dtype else a.to(g.dtype)
+            t.g = g
         # a mean-reduced loss hands back gradients divided by B; undo it (Opacus: loss_reduction)
         scale = float(B) if self.module.loss_reduction == "mean" else 1.0
         coef = torch.empty(B, dtype=torch.float32, device=dev)
         norms = torch.empty(B, dtype=torch.float32, device=dev)
-        check(lib.vqaf_clip_coef(ptr(sq), B, self.max_grad_norm, scale, ptr(coef), ptr(norms), st),
-              "vqaf_clip_coef")
+        n = len(tapes)
+        same_dtype = all(t.g.dtype == tapes[0].g.dtype for t in tapes)
+        if n <= 8 and same_dtype:
+            import ctypes
+            pa = (ctypes.c_void_p * n)(*[ptr(t.a) for t in tapes])
+            pg = (ctypes.c_void_p * n)(*[ptr(t.g) for t in tapes])
+            din = (ctypes.c_int * n)(*[t.a.shape[1] for t in tapes])
+            dout = (ctypes.c_int * n)(*[t.g.shape[1] for t in tapes])
+            kind = (ctypes.c_int * n)(*[2 if t.kind != "linear" else int(t.module.bias is not None)
+                                        for t in tapes])
+            check(lib.vqaf_ghost_clip(n, pa, pg, din, dout, kind, B, dtype_code(tapes[0].g),
+                                      self.max_grad_norm, scale, ptr(coef), ptr(norms), None, st),
+                  "vqaf_ghost_clip")
+        else:
+            sq = torch.empty(B, dtype=torch.float32, device=dev)
+            for i, t in enumerate(tapes):
+                a, g = t.a, t.g
+                if t.kind == "linear":
+                    check(lib.vqaf_ghost_sqnorm_linear(ptr(a), ptr(g), B, a.shape[1], g.shape[1],
+                                                       dtype_code(g), int(t.module.bias is not None),
+                                                       int(i > 0), ptr(sq), st), "vqaf_ghost_sqnorm_linear")
+                else:
+                    check(lib.vqaf_ghost_sqnorm_affine(ptr(a), ptr(g), B, g.shape[1], dtype_code(g),
+                                                       int(i > 0), ptr(sq), st), "vqaf_ghost_sqnorm_affine")
+            check(lib.vqaf_clip_coef(ptr(sq), B, self.max_grad_norm, scale, ptr(coef), ptr(norms), st),
+                  "vqaf_clip_coef")
         self.last_norms, self.last_clip = norms, coef / scale
         for t in tapes:
             a, g = t.a, t.g.contiguous()

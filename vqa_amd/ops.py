@@ -103,19 +103,17 @@ def head_score_matrix(q: torch.Tensor, seq: torch.Tensor, in_proj_weight: torch.
     B, N, D = seq.shape
     H = num_heads
     seq = seq.contiguous()
+    ptr(seq)  # fails loudly on CPU tensors before any device call
     q = q.reshape(B, D).to(seq.dtype).contiguous()
     w_ = in_proj_weight.detach().contiguous()
     b_ = in_proj_bias.detach().to(w_.dtype).contiguous()
     lib, st, dev = load(), stream_ptr(seq.device), seq.device
     qp = torch.empty(B, D, dtype=torch.float32, device=dev)
     u = torch.empty(B, H, D, dtype=torch.float32, device=dev)
-    split = None
-    if dtype_code(seq) == _lib.BF16 and H <= 8 and D in (64, 128, 256, 512, 768, 1024):
-        split = torch.empty(B, 16, D, dtype=torch.bfloat16, device=dev)
     check(lib.vqaf_fold_query(ptr(q), ptr(w_), ptr(b_), B, D, H, dtype_code(seq), dtype_code(w_), ptr(qp),
-                              ptr(u), ptr(split), st), "vqaf_fold_query")
+                              ptr(u), st), "vqaf_fold_query")
     s = torch.empty(B, N, H, dtype=torch.float32, device=dev)
-    check(lib.vqaf_head_scores(ptr(seq), ptr(u), ptr(split), B, N, D, H, dtype_code(seq), ptr(s), st),
+    check(lib.vqaf_head_scores(ptr(seq), ptr(u), B, N, D, H, dtype_code(seq), ptr(s), st),
           "vqaf_head_scores")
     return s
 

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ._lib import BF16, check, dtype_code, load, ptr, stream_ptr
+from ._lib import check, dtype_code, load, ptr, stream_ptr
 
 
 def _head_scores(seq: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
@@ -24,12 +24,7 @@ def _head_scores(seq: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
     H = u.shape[1]
     lib, st = load(), stream_ptr(seq.device)
     s = torch.empty(B, N, H, dtype=torch.float32, device=seq.device)
-    split = None
-    if dtype_code(seq) == BF16 and H <= 8 and D in (64, 128, 256, 512, 768, 1024):
-        split = torch.empty(B, 16, D, dtype=torch.bfloat16, device=seq.device)
-        check(lib.vqaf_split_u(ptr(u), B, H, D, ptr(split), st), "vqaf_split_u")
-    check(lib.vqaf_head_scores(ptr(seq), ptr(u), ptr(split), B, N, D, H, dtype_code(seq), ptr(s), st),
-          "vqaf_head_scores")
+    check(lib.vqaf_head_scores(ptr(seq), ptr(u), B, N, D, H, dtype_code(seq), ptr(s), st), "vqaf_head_scores")
     return s
 
 
