@@ -8,7 +8,10 @@ COCO-QA-shaped inputs already resident in HBM (encoders are outside the hot path
 zero_grad -> CoAttention(pruning, keep 0.5, adversarial mixing) forward -> classifier forward ->
 mean CE -> backward (classifier input gradients, fusion input gradients) -> per-sample norms,
 clip (C = 1.0), clipped sums, Gaussian noise (sigma = 1.0), RCCL all-reduce, AdamW step.
-Logical batch 1024 is sharded over the ranks (strong scaling, BASELINE.json configs[2]).
+At N = 1 this is BASELINE.json configs[2] (logical batch 1024) on one GPU.  For N > 1 the default
+keeps the per-GPU batch at 1024 (weak scaling: logical batch 1024*N, `value` = all samples / time);
+`--scaling strong` shards the literal logical batch 1024 instead, and an N > 1 run also reports that
+sharded configuration under "strong_scaling_1024" so both readings of configs[2] are measured.
 
 Rank 0 prints ONE JSON line: whole-job samples/s plus a `roofline` object for the prune+mix
 kernel (timed live with stream events inside the timed region), a `cpu_baseline` object (the
@@ -41,9 +44,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=LOGICAL_BATCH, help="logical (whole-job) batch")
+    ap.add_argument("--batch", type=int, default=LOGICAL_BATCH,
+                    help="per-GPU batch (weak scaling) or logical whole-job batch (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graph)")
+    ap.add_argument("--graph-multi", action="store_true",
+                    help="with N > 1 also replay the two compute phases as HIP graphs around the eager "
+                         "RCCL all-reduce (default for N > 1 is eager launches: the graph + collective "
+                         "combination could not be validated on a one-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=64)
@@ -71,7 +80,7 @@ class Probe:
         return sum(a.elapsed_time(b) for a, b in self.pairs) / max(1, len(self.pairs))
 
 
-def build_job(dev, local_b, dtype, rank):
+def build_job(dev, local_b, dtype, rank, logical_b=LOGICAL_BATCH):
     from vqa_amd import dp, fusion
     torch.manual_seed(42)  # the reference's seed (train.py:19): identical parameters on all ranks
     fus = fusion.CoAttention(embed_dim=D, num_heads=8, use_pruning=True, prune_ratio=1 - KEEP,
@@ -85,7 +94,7 @@ def build_job(dev, local_b, dtype, rank):
     gsm = dp.GradSampleModule(cls)
     inner = torch.optim.AdamW(cls.parameters(), lr=1e-4, weight_decay=0.01, fused=True, capturable=True)
     opt = dp.DPOptimizer(inner, gsm, noise_multiplier=1.0, max_grad_norm=1.0,
-                         expected_batch_size=LOGICAL_BATCH, seed=1234)
+                         expected_batch_size=logical_b, seed=1234)
     main_opt = torch.optim.AdamW(fus.parameters(), lr=1e-4, weight_decay=0.01, fused=True, capturable=True)
     # four rotating input sets: > 256 MiB of tokens in total, so no set survives in the
     # Infinity Cache from one use to the next
@@ -100,9 +109,12 @@ def build_job(dev, local_b, dtype, rank):
 
 
 def make_step(fus, gsm, opt, main_opt, sets):
+    """The training step in the order of utils/src.py:66-106, split at the one collective:
+    `local(i)` = zero_grad, forward, loss, backward, main step, per-rank DP work;
+    `reduce()` = the gradient all-reduce (RCCL; nothing at N = 1); `apply()` = the DP update."""
     from vqa_amd import ops
 
-    def step(i):
+    def local(i):
         v, vg, q, qg, y = sets[i % len(sets)]
         v.grad = None
         q.grad = None
@@ -113,9 +125,15 @@ def make_step(fus, gsm, opt, main_opt, sets):
         loss = ops.cross_entropy_mean(logits, y)
         loss.backward()
         main_opt.step()
-        opt.step()
+        opt.local_step()
         return loss
 
+    def step(i):
+        local(i)
+        opt.reduce_step()
+        opt.apply_step()
+
+    step.local, step.reduce, step.apply = local, opt.reduce_step, opt.apply_step
     return step
 
 
@@ -194,85 +212,128 @@ def cpu_baseline(sample):
                       f"per-sample grads by vmap)"}
 
 
-def main():
-    args = parse()
+def run_job(args, dev, dtype, rank, world, local_b, logical_b, probe):
+    """Builds the job at the given per-rank batch, captures it, times `steps` steps.
+    Returns (seconds for the timed steps (max over ranks), launch mode, eager ms/step or None)."""
     from vqa_amd import dist as vdist
-    from vqa_amd import ops
-    rank, local, world = vdist.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    lo, hi = vdist.shard_range(args.batch, rank, world)
-    local_b = hi - lo
-
-    fus, gsm, opt, main_opt, sets = build_job(dev, local_b, dtype, rank)
+    fus, gsm, opt, main_opt, sets = build_job(dev, local_b, dtype, rank, logical_b)
     step = make_step(fus, gsm, opt, main_opt, sets)
-    probe = Probe("gather_mix_pool:0")
-    ops.PROBE = probe
-
     # eager warm-up: creates every lazily built buffer (flat gradient bucket, RNG states, RCCL
     # communicators) before anything is captured
     for i in range(max(args.warmup, len(sets))):
         step(i)
     torch.cuda.synchronize()
-    graphs = None
-    if not args.eager:
-        # the launch-bound step (about 70 short kernels) is captured once per input set into a HIP
+    graphs = g_apply = None
+    if not args.eager and (world == 1 or args.graph_multi):
+        # the launch-bound step (about 60 short kernels) is captured once per input set into a HIP
         # graph; replays draw fresh noise because the RNG counters live in device memory
+        # With several ranks the collective stays OUT of the graphs: one graph per input set for
+        # the work before it, one for the update after it, and a plain RCCL all-reduce between.
         try:
             graphs, pool = [], None
             for i in range(len(sets)):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
-                    step(i)
+                    if world == 1:
+                        step(i)
+                    else:
+                        step.local(i)
                 pool = g.pool()
                 graphs.append(g)
+            g_apply = None
+            if world > 1:
+                g_apply = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_apply, pool=pool):
+                    step.apply()
             for g in graphs:
                 g.replay()
+                if g_apply is not None:
+                    step.reduce()
+                    g_apply.replay()
             torch.cuda.synchronize()
         except Exception as exc:  # capture is an optimisation of the launch path only
             if rank == 0:
                 print(f"[bench] HIP graph capture unavailable ({type(exc).__name__}: {exc}); "
                       "timing eager launches", file=sys.stderr)
-            graphs = None
+            graphs = g_apply = None
             torch.cuda.synchronize()
 
     def run(i):
-        if graphs is not None:
-            graphs[i % len(graphs)].replay()
-        else:
+        if graphs is None:
             step(i)
+        else:
+            graphs[i % len(graphs)].replay()
+            if g_apply is not None:
+                step.reduce()
+                g_apply.replay()
 
     for i in range(args.warmup):
         run(i)
     vdist.barrier()
     torch.cuda.synchronize()
-    probe.enabled = graphs is None
+    if probe is not None:
+        probe.enabled = graphs is None
     t0 = time.perf_counter()
     for i in range(args.steps):
         run(args.warmup + i)
     torch.cuda.synchronize()
     vdist.barrier()
     dt = time.perf_counter() - t0
-    probe.enabled = False
     eager_ms = None
-    if graphs is not None:
-        # stream events cannot be read back from inside a replayed graph, so the prune+mix kernel
-        # is timed over the same number of eagerly launched steps right after the timed region
-        probe.enabled = True
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        torch.cuda.synchronize()
-        eager_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    if probe is not None:
         probe.enabled = False
+        if graphs is not None:
+            # stream events cannot be read back from inside a replayed graph, so the prune+mix
+            # kernel is timed over the same number of eagerly launched steps right afterwards
+            probe.enabled = True
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                step(args.warmup + i)
+            torch.cuda.synchronize()
+            eager_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            probe.enabled = False
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    return dt, ("hipgraph" if graphs is not None else "eager"), eager_ms
+
+
+def main():
+    args = parse()
+    if os.environ.get("VQAF_BENCH_WATCHDOG"):  # developer aid: dump all stacks if a rehearsal stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["VQAF_BENCH_WATCHDOG"]), exit=True)
+    from vqa_amd import dist as vdist
+    from vqa_amd import ops
+    rank, local, world = vdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    dev = vdist.local_device(local)
+    torch.cuda.set_device(dev)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.scaling == "weak":
+        local_b, logical_b = args.batch, args.batch * world
+    else:
+        lo, hi = vdist.shard_range(args.batch, rank, world)
+        local_b, logical_b = hi - lo, args.batch
+
+    probe = Probe("gather_mix_pool:0")
+    ops.PROBE = probe
+    dt, launch, eager_ms = run_job(args, dev, dtype, rank, world, local_b, logical_b, probe)
+    ops.PROBE = None
+    other = None
+    if world > 1:  # the other reading of configs[2]: same logical batch 1024, sharded
+        if args.scaling == "weak":
+            lo, hi = vdist.shard_range(args.batch, rank, world)
+            o_local, o_logical, o_name = hi - lo, args.batch, "strong_scaling_1024"
+        else:
+            o_local, o_logical, o_name = args.batch, args.batch * world, "weak_scaling_1024_per_gpu"
+        o_dt, o_launch, _ = run_job(args, dev, dtype, rank, world, o_local, o_logical, None)
+        other = (o_name, {"value": round(o_logical * args.steps / o_dt, 1), "unit": "samples/s",
+                          "global_batch": o_logical, "per_gpu_batch": o_local,
+                          "ms_per_step": round(o_dt / args.steps * 1e3, 4), "launch": o_launch})
 
     if rank == 0:
         s = 2 if dtype == torch.bfloat16 else 4
@@ -292,23 +353,26 @@ def main():
             traffic = None
         line = {
             "metric": "DP-SGD train samples/s (fusion+classifier+DP step, token-level inputs)",
-            "value": round(args.batch * args.steps / dt, 1),
+            "value": round(logical_b * args.steps / dt, 1),
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "launch": "hipgraph" if graphs is not None else "eager",
+            "launch": launch,
             "ms_per_step_eager": round(eager_ms, 4) if eager_ms is not None else None,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: DP-SGD step, C=1.0, sigma=1.0, logical batch "
-                                   f"{args.batch} sharded over {world} GPU(s); CoAttention pruning keep 0.5, "
-                                   f"{N_VIS} vision + {N_TXT} text tokens x {D}, {C} classes; encoders bypassed",
-                       "global_batch": args.batch, "per_gpu_batch": local_b, "parallelism": f"dp{world}"},
+            "config": {"workload": "BASELINE configs[2]: DP-SGD step, C=1.0, sigma=1.0, "
+                                   f"logical batch {logical_b} = {local_b} per GPU x {world} GPU(s); "
+                                   f"CoAttention pruning keep 0.5, {N_VIS} vision + {N_TXT} text tokens x {D}, "
+                                   f"{C} classes; encoders bypassed",
+                       "global_batch": logical_b, "per_gpu_batch": local_b, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": "gather_mix_kernel<pool> (vision tokens)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(k_ms, 5), "algorithmic_bytes": alg_bytes},
         }
+        if other is not None:
+            line[other[0]] = other[1]
         if not args.no_sweep:
             line["prune_mix_cfg4"] = prune_mix_sweep(dev, dtype)
         if not args.no_cpu_baseline and world == 1:

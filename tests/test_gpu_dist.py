@@ -1,0 +1,84 @@
+"""GPU: the data-parallel DP-SGD step with two ranks.  The box has one GPU, so both ranks share
+cuda:0 and exchange through gloo; what is checked is the logic RCCL runs unchanged on 8 GPUs:
+shard -> per-rank clip/sum -> noise share -> sum all-reduce -> identical fused AdamW on every rank,
+and equality with the single-process step on the whole batch when the noise is off."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from oracle import dp_oracle as do
+from oracle import inputs as gi
+
+pytestmark = pytest.mark.gpu
+IN, HID, C, B = 128, 256, 100, 24
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model(dev):
+    m = do.make_classifier(IN, HID, C, dp_fixed=True)
+    m.load_state_dict(gi.classifier_params(60, IN, HID, C))
+    return m.eval().to(dev)
+
+
+def _step(dev, x, y, sigma, expected, steps=2):
+    from vqa_amd import dp
+    m = _model(dev)
+    gsm = dp.GradSampleModule(m)
+    opt = dp.DPOptimizer(torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=0.01), gsm,
+                         noise_multiplier=sigma, max_grad_norm=1.0, expected_batch_size=expected, seed=7)
+    first_grad = None
+    for _ in range(steps):
+        opt.zero_grad()
+        nn.CrossEntropyLoss()(gsm(x), y).backward()
+        opt.step()
+        if first_grad is None:
+            first_grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu()
+    return torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu(), first_grad
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), VQAF_DIST_BACKEND="gloo", VQAF_SINGLE_DEVICE="1")
+    from vqa_amd import dist as vdist
+    r, local, w = vdist.init_from_env()
+    dev = vdist.local_device(local)
+    torch.cuda.set_device(dev)
+    x, y = gi.normal(1, B, IN).to(dev), gi.labels(2, B, C).to(dev)
+    lo, hi = vdist.shard_range(B, rank, world)
+    quiet, quiet_grad = _step(dev, x[lo:hi], y[lo:hi], 0.0, B)
+    noisy, _ = _step(dev, x[lo:hi], y[lo:hi], 1.0, B)
+    torch.save({"quiet": quiet, "noisy": noisy, "quiet_grad": quiet_grad}, os.path.join(out_dir, f"r{rank}.pt"))
+    vdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_share_one_gpu_over_gloo(tmp_path):
+    assert torch.cuda.is_available()
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "r0.pt"), weights_only=True)
+    r1 = torch.load(os.path.join(str(tmp_path), "r1.pt"), weights_only=True)
+    # replicas stay bit-identical: every rank applies the same reduced gradient
+    assert torch.equal(r0["quiet"], r1["quiet"]) and torch.equal(r0["noisy"], r1["noisy"])
+    # noise off: two shards == one process on the whole batch (per-sample clipping is rank-local)
+    dev = torch.device("cuda:0")
+    x, y = gi.normal(1, B, IN).to(dev), gi.labels(2, B, C).to(dev)
+    single, single_grad = _step(dev, x, y, 0.0, B)
+    gs = float(single_grad.abs().max())
+    np.testing.assert_allclose(r0["quiet_grad"].numpy(), single_grad.numpy(), rtol=1e-5, atol=2e-6 * gs)
+    # Adam divides by sqrt(v): where a gradient is ~0 the last bits of the sum order decide the
+    # update's sign, so parameters agree to a fraction of one lr-sized step, not to f32 rounding
+    np.testing.assert_allclose(r0["quiet"].numpy(), single.numpy(), rtol=1e-3, atol=2e-4)
+    # noise on: the parameters moved away from the noise-free ones by a noise-sized amount
+    assert float((r0["noisy"] - r0["quiet"]).abs().max()) > 1e-4

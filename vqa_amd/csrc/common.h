@@ -12,6 +12,14 @@
     if (!(cond)) return (code);  \
   } while (0)
 
+// hipGetLastError() is sticky per thread: an error left behind by an unrelated earlier runtime
+// call (for example an aborted stream capture) would otherwise be blamed on the next launch.
+// Every entry point therefore clears it first and reports only what its own launches raise.
+struct VqafEntryScope {
+  VqafEntryScope() { (void)hipGetLastError(); }
+};
+#define VQAF_ENTRY() VqafEntryScope vqaf_entry_scope_
+
 #define VQAF_LAUNCH_CHECK() \
   do { return hipGetLastError() == hipSuccess ? VQAF_OK : VQAF_E_LAUNCH; } while (0)
 

@@ -751,6 +751,7 @@ bool gn_shape_ok(int C, int groups) {
 extern "C" int vqaf_ghost_sqnorm_linear(const void* a, const void* g, int B, int In, int Out,
                                         int dtype, int has_bias, int accumulate, float* sq,
                                         vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(a && g && sq, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && In > 0 && Out > 0, VQAF_E_SHAPE);
@@ -761,6 +762,7 @@ extern "C" int vqaf_ghost_sqnorm_linear(const void* a, const void* g, int B, int
 
 extern "C" int vqaf_ghost_sqnorm_affine(const void* xhat, const void* g, int B, int C, int dtype,
                                         int accumulate, float* sq, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(xhat && g && sq, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && C > 0, VQAF_E_SHAPE);
@@ -771,6 +773,7 @@ extern "C" int vqaf_ghost_sqnorm_affine(const void* xhat, const void* g, int B, 
 
 extern "C" int vqaf_clip_coef(const float* sq, int B, float max_norm, float scale, float* coef,
                               float* norms, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(sq && coef, VQAF_E_NULL);
   VQAF_REQUIRE(B > 0, VQAF_E_SHAPE);
   hipLaunchKernelGGL(clip_coef_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
@@ -782,6 +785,7 @@ extern "C" int vqaf_ghost_clip(int n_layers, const void* const* a_host, const vo
                                const int* in_dim_host, const int* out_dim_host, const int* kind_host,
                                int B, int dtype, float max_norm, float scale, float* coef, float* norms,
                                float* sq, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(a_host && g_host && in_dim_host && out_dim_host && kind_host && coef, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && n_layers > 0 && n_layers <= GC_MAX_LAYERS, VQAF_E_SHAPE);
@@ -812,6 +816,7 @@ extern "C" int vqaf_ghost_clip(int n_layers, const void* const* a_host, const vo
 extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float* coef, int B,
                                        int In, int Out, int dtype, int accumulate, float* SW,
                                        float* Sb, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(a && g && coef && SW, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && In > 0 && Out > 0, VQAF_E_SHAPE);
@@ -848,6 +853,7 @@ extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float
 extern "C" int vqaf_clipped_sum_affine(const void* xhat, const void* g, const float* coef, int B,
                                        int C, int dtype, int accumulate, float* Sgamma,
                                        float* Sbeta, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(xhat && g && coef, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && C > 0, VQAF_E_SHAPE);
@@ -871,6 +877,7 @@ extern "C" int vqaf_clipped_sum_affine(const void* xhat, const void* g, const fl
 extern "C" int vqaf_noise_scale(const float* S, const float* noise, const uint64_t* rng_state,
                                 float noise_std, float scale, size_t n, float* grad,
                                 vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(S && grad, VQAF_E_NULL);
   VQAF_REQUIRE(n > 0, VQAF_E_SHAPE);
   VQAF_REQUIRE(noise != nullptr || noise_std == 0.f || rng_state != nullptr, VQAF_E_NULL);
@@ -889,6 +896,7 @@ extern "C" int vqaf_dp_adamw(const float* S, const float* noise, const uint64_t*
                              float* exp_avg_sq, void* shadow_bf16, float* grad_out, size_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay,
                              const uint64_t* step, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(S && param && exp_avg && exp_avg_sq && step, VQAF_E_NULL);
   VQAF_REQUIRE(n > 0, VQAF_E_SHAPE);
   VQAF_REQUIRE(noise != nullptr || noise_std == 0.f || rng_state != nullptr, VQAF_E_NULL);
@@ -910,6 +918,7 @@ extern "C" int vqaf_dp_adamw(const float* S, const float* noise, const uint64_t*
 extern "C" int vqaf_groupnorm_fwd(const void* x, const void* gamma, const void* beta, int B, int C,
                                   int groups, float eps, int relu, int dtype, void* y, void* xhat,
                                   float* rstd, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(x && gamma && beta && y && xhat && rstd, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && C > 0 && gn_shape_ok(C, groups), VQAF_E_SHAPE);
@@ -924,6 +933,7 @@ extern "C" int vqaf_groupnorm_bwd(const void* grad_y, const void* y, const void*
                                   const float* rstd, const void* gamma, int B, int C, int groups,
                                   int relu, int dtype, void* g_pre, void* grad_x,
                                   vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(grad_y && xhat && rstd && gamma && g_pre && grad_x, VQAF_E_NULL);
   VQAF_REQUIRE(!relu || y != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
@@ -938,6 +948,7 @@ extern "C" int vqaf_groupnorm_bwd(const void* grad_y, const void* y, const void*
 extern "C" int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, int C, int dtype,
                             float* loss, float* conf, int64_t* pred, float* grad_logits,
                             float grad_scale, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(logits != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE((loss == nullptr && grad_logits == nullptr) || targets != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
@@ -949,7 +960,8 @@ extern "C" int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, i
   VQAF_LAUNCH_CHECK();
 }
 
-extern "C" int vqaf_version(void) { return VQAF_VERSION; }
+extern "C" int vqaf_version(void) {
+  VQAF_ENTRY(); return VQAF_VERSION; }
 
 extern "C" const char* vqaf_status_string(int status) {
   switch (status) {

@@ -600,6 +600,7 @@ extern "C" int vqaf_gather_mix(const void* seq, const int64_t* idx, const float*
                                int noise_kind, float noise_scale, const uint64_t* rng_state,
                                float alpha, int B, int N, int K, int D, int dtype, int out_dtype,
                                void* out, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   const int rc = check_common(seq, idx, B, N, K, D, dtype, out_dtype);
   if (rc != VQAF_OK) return rc;
   VQAF_REQUIRE(out != nullptr, VQAF_E_NULL);
@@ -615,6 +616,7 @@ extern "C" int vqaf_gather_mix_pool(const void* seq, const int64_t* idx, const f
                                     int noise_kind, float noise_scale, const uint64_t* rng_state,
                                     float alpha, int B, int N, int K, int D, int dtype, void* out,
                                     int ld_out, int col0, int out_dtype, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   const int rc = check_common(seq, idx, B, N, K, D, dtype, out_dtype);
   if (rc != VQAF_OK) return rc;
   VQAF_REQUIRE(out != nullptr, VQAF_E_NULL);
@@ -629,6 +631,7 @@ extern "C" int vqaf_gather_mix_pool(const void* seq, const int64_t* idx, const f
 extern "C" int vqaf_gather_mix_bwd(const void* grad_out, const int64_t* idx, float alpha, int B,
                                    int N, int K, int D, int g_dtype, int dtype, void* grad_seq,
                                    vqaf_stream_t stream) {
+  VQAF_ENTRY();
   const int rc = check_common(grad_out, idx, B, N, K, D, g_dtype, dtype);
   if (rc != VQAF_OK) return rc;
   VQAF_REQUIRE(grad_seq != nullptr, VQAF_E_NULL);
@@ -640,6 +643,7 @@ extern "C" int vqaf_gather_mix_bwd(const void* grad_out, const int64_t* idx, flo
 extern "C" int vqaf_gather_mix_pool_bwd(const void* grad_out, int ld_out, int col0, int g_dtype,
                                         const int64_t* idx, float alpha, int B, int N, int K,
                                         int D, int dtype, void* grad_seq, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(grad_out != nullptr && idx != nullptr && grad_seq != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(g_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && N > 0 && K > 0 && K <= N && D > 0 && N <= 16384 && B <= 65535, VQAF_E_SHAPE);
@@ -651,6 +655,7 @@ extern "C" int vqaf_gather_mix_pool_bwd(const void* grad_out, int ld_out, int co
 
 extern "C" int vqaf_mean_pool(const void* x, int B, int M, int D, int dtype, void* out, int ld_out,
                               int col0, int out_dtype, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(x != nullptr && out != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(out_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && M > 0 && D > 0 && B <= 65535, VQAF_E_SHAPE);
@@ -679,6 +684,7 @@ extern "C" int vqaf_mean_pool(const void* x, int B, int M, int D, int dtype, voi
 
 extern "C" int vqaf_mean_pool_bwd(const void* grad_out, int ld_out, int col0, int g_dtype, int B,
                                   int M, int D, int dtype, void* grad_x, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(grad_out != nullptr && grad_x != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(g_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && M > 0 && D > 0 && B <= 65535, VQAF_E_SHAPE);

@@ -183,6 +183,7 @@ extern "C" int vqaf_gemm_f32(const void* A, int a_dtype, long a_sg, long a_sm, l
                              const void* bias, int bias_dtype, long bias_sg, float* C, long c_sg,
                              long c_sm, int G, int M, int N, int K, float alpha, int beta_one,
                              vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(A != nullptr && Bm != nullptr && C != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(a_dtype) && vqaf_dtype_ok(b_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(bias == nullptr || vqaf_dtype_ok(bias_dtype), VQAF_E_DTYPE);

@@ -258,6 +258,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" int vqaf_fold_query(const void* q, const void* in_proj_weight, const void* in_proj_bias,
                                int B, int D, int H, int dtype, int w_dtype, float* qproj_ws,
                                float* u, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(q && in_proj_weight && in_proj_bias && qproj_ws && u, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(w_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && D > 0 && H > 0 && D % H == 0, VQAF_E_SHAPE);
@@ -279,6 +280,7 @@ static bool mfma_steps_ok(int D) {
 
 extern "C" int vqaf_head_scores(const void* seq, const float* u, int B, int N, int D, int H,
                                 int dtype, float* s, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(seq && u && s, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && N > 0 && D > 0 && H > 0 && B <= 65535, VQAF_E_SHAPE);
@@ -345,6 +347,7 @@ extern "C" int vqaf_head_scores(const void* seq, const float* u, int B, int N, i
 
 extern "C" int vqaf_attn_weights(const float* s, int B, int N, int H, float* w,
                                  vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(s && w, VQAF_E_NULL);
   VQAF_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 16, VQAF_E_SHAPE);
   const int HP = pad_heads(H);
@@ -370,6 +373,7 @@ extern "C" int vqaf_score(const void* q, const void* seq, const void* in_proj_we
                           const void* in_proj_bias, int B, int N, int D, int H, int dtype,
                           int w_dtype, void* workspace, size_t workspace_bytes, float* w,
                           vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(workspace != nullptr && w != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(B > 0 && N > 0 && D > 0 && H > 0, VQAF_E_SHAPE);
   VQAF_REQUIRE(workspace_bytes >= vqaf_score_workspace_bytes(B, N, D, H), VQAF_E_SHAPE);

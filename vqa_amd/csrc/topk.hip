@@ -207,6 +207,7 @@ inline int sort_threads(int NP) {
 
 extern "C" int vqaf_topk(const float* w, int B, int N, int K, int64_t* top, int64_t* bottom,
                          vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(w != nullptr && top != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(B > 0 && N > 0 && K > 0 && K <= N && N <= TK_MAX_N, VQAF_E_SHAPE);
   const int NP = next_pow2(N);
@@ -218,6 +219,7 @@ extern "C" int vqaf_topk(const float* w, int B, int N, int K, int64_t* top, int6
 extern "C" int vqaf_adv_swap(int64_t* top, const int64_t* bottom, const int64_t* pos,
                              const int64_t* src, int B, int K, int R, int k_adv,
                              vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(top != nullptr && bottom != nullptr && pos != nullptr && src != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(B > 0 && K > 0 && R > 0 && k_adv > 0 && k_adv <= K && k_adv <= R, VQAF_E_SHAPE);
   hipLaunchKernelGGL(adv_swap_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, top, bottom, pos,
@@ -228,6 +230,7 @@ extern "C" int vqaf_adv_swap(int64_t* top, const int64_t* bottom, const int64_t*
 extern "C" int vqaf_adv_swap_random(int64_t* top, const int64_t* bottom, int B, int K, int R,
                                     int k_adv, const uint64_t* rng_state, int64_t* pos_out,
                                     int64_t* src_out, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(top != nullptr && bottom != nullptr && rng_state != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(B > 0 && K > 0 && R > 0 && k_adv > 0 && k_adv <= K && k_adv <= R, VQAF_E_SHAPE);
   VQAF_REQUIRE(K <= TK_MAX_N && R <= TK_MAX_N && k_adv <= TK_MAX_N / 2, VQAF_E_SHAPE);
@@ -243,6 +246,7 @@ extern "C" int vqaf_select(const float* s, const float* w_in, int B, int N, int 
                            int k_adv, const int64_t* pos, const int64_t* src,
                            const uint64_t* rng_state, float* w_out, int64_t* top, int64_t* bottom,
                            int64_t* pos_out, int64_t* src_out, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE((s != nullptr) != (w_in != nullptr), VQAF_E_NULL);  // exactly one source of weights
   VQAF_REQUIRE(top != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(B > 0 && N > 0 && K > 0 && K <= N && N <= TK_MAX_N, VQAF_E_SHAPE);
@@ -265,6 +269,7 @@ extern "C" int vqaf_select(const float* s, const float* w_in, int B, int N, int 
 }
 
 extern "C" int vqaf_rng_advance(uint64_t* rng_state, uint64_t delta, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(rng_state != nullptr, VQAF_E_NULL);
   hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rng_state, delta);
   VQAF_LAUNCH_CHECK();

@@ -230,6 +230,7 @@ inline int pad_heads(int H) {
   }
 
 extern "C" int vqaf_softmax_heads(const float* s, int B, int N, int H, float* p, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(s && p, VQAF_E_NULL);
   VQAF_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 16, VQAF_E_SHAPE);
   const int HP = pad_heads(H);
@@ -239,6 +240,7 @@ extern "C" int vqaf_softmax_heads(const float* s, int B, int N, int H, float* p,
 
 extern "C" int vqaf_softmax_heads_bwd(const float* p, const float* dp, int B, int N, int H, float* ds,
                                       vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(p && dp && ds, VQAF_E_NULL);
   VQAF_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 16, VQAF_E_SHAPE);
   const int HP = pad_heads(H);
@@ -248,6 +250,7 @@ extern "C" int vqaf_softmax_heads_bwd(const float* p, const float* dp, int B, in
 
 extern "C" int vqaf_weighted_token_sum(const void* seq, const float* c, int B, int N, int D, int H,
                                        int dtype, float* z, vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(seq && c && z, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && N > 0 && D > 0 && H > 0 && H <= 16 && B <= 65535, VQAF_E_SHAPE);
@@ -280,6 +283,7 @@ extern "C" int vqaf_weighted_token_sum(const void* seq, const float* c, int B, i
 extern "C" int vqaf_token_outer(const float* ca, const float* va, const float* cb, const float* vb,
                                 int B, int N, int D, int H, int dtype, void* out,
                                 vqaf_stream_t stream) {
+  VQAF_ENTRY();
   VQAF_REQUIRE(ca && va && cb && vb && out, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && N > 0 && D > 0 && H > 0 && H <= 8 && B <= 65535, VQAF_E_SHAPE);

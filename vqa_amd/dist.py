@@ -24,11 +24,21 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # VQAF_DIST_BACKEND=gloo rehearses the multi-rank path where RCCL cannot run
+            # (CPU-only hosts, or several ranks sharing one GPU)
+            backend = os.environ.get("VQAF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def local_device(local_rank: int) -> torch.device:
+    """cuda:<local_rank>, or cuda:0 for every rank when VQAF_SINGLE_DEVICE=1 (rehearsal of N ranks
+    on a one-GPU box; only meaningful with the gloo backend)."""
+    if os.environ.get("VQAF_SINGLE_DEVICE") == "1":
+        return torch.device("cuda", 0)
+    return torch.device("cuda", local_rank)
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:

@@ -249,6 +249,7 @@ class DPOptimizer:
         self._rng = None
         self._seed = seed
         self._P = self._M = self._V = self._shadow = self._step = None
+        self._use_fused = False
         self.last_norms = None
         self.last_clip = None
 
@@ -329,19 +330,18 @@ class DPOptimizer:
             self.module.shadow = lookup
 
     @torch.no_grad()
-    def _fused_step(self, noise: Optional[torch.Tensor] = None):
-        """(all-reduce) + noise + scale + AdamW + bf16 refresh in one pass per parameter group."""
-        import torch.distributed as dist
+    def _fused_apply(self, noise: Optional[torch.Tensor] = None):
+        """noise + scale + AdamW + bf16 refresh in one pass per parameter group.  With one rank the
+        kernel reads the clipped sums and adds the noise itself; in a process group it reads the
+        already noised, scaled and all-reduced gradient bucket."""
         S, grad = self._S, self._grad
         dev = S.device
         self._fused_buffers(dev)
         lib, st = load(), stream_ptr(dev)
         world, _ = self._world()
-        std = self.noise_multiplier * self.max_grad_norm / math.sqrt(world)
-        scale = 1.0 / self.expected_batch_size
-        src = S
-        if world > 1:
-            self.add_noise_and_scale(noise)   # per-rank noise share, scale, sum all-reduce -> grad
+        if world == 1:
+            src, std, scale = S, self.noise_multiplier * self.max_grad_norm, 1.0 / self.expected_batch_size
+        else:
             src, std, scale, noise = grad, 0.0, 1.0, None
         for group in self.original_optimizer.param_groups:
             ps = [p for p in group["params"] if id(p) in self._offsets]
@@ -359,6 +359,15 @@ class DPOptimizer:
             if world == 1 and nz is None and std != 0.0:
                 self._rng.advance()  # a fresh stream for the next group / step
         check(lib.vqaf_rng_advance(ptr(self._step), 1, st), "vqaf_rng_advance")
+
+    def _fused_step(self, noise: Optional[torch.Tensor] = None):
+        """(tests) fused path with an injected noise tensor, after clip_and_accumulate()."""
+        world, _ = self._world()
+        self._use_fused = True
+        if world > 1:
+            self._noise_scale_local(noise)
+            self.reduce_step()
+        self._fused_apply(noise)
 
     def _slice(self, buf, p):
         o = self._offsets[id(p)]
@@ -427,42 +436,69 @@ class DPOptimizer:
         return S
 
     @torch.no_grad()
-    def add_noise_and_scale(self, noise: Optional[torch.Tensor] = None):
-        """grad = (S + sigma C z) / expected_batch_size.  In a process group every rank adds its
-        own N(0, (sigma C)^2 / world) share BEFORE the all-reduce, so the sum carries exactly
-        one N(0, (sigma C)^2).  `noise` injects z (tests)."""
-        import torch.distributed as dist
+    def _noise_scale_local(self, noise: Optional[torch.Tensor] = None):
+        """grad = (S + (sigma C / sqrt(world)) z) / expected_batch_size on this rank (no exchange)."""
         S, grad = self._S, self._grad
-        world, rank = self._world()
+        world, _ = self._world()
         std = self.noise_multiplier * self.max_grad_norm / math.sqrt(world)
         check(load().vqaf_noise_scale(ptr(S), ptr(noise), ptr(self._rng.state), std,
                                       1.0 / self.expected_batch_size, self._numel, ptr(grad),
                                       stream_ptr(S.device)), "vqaf_noise_scale")
         if noise is None and std != 0.0:
             self._rng.advance()
-        if world > 1:
-            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.process_group)
         return grad
+
+    @torch.no_grad()
+    def add_noise_and_scale(self, noise: Optional[torch.Tensor] = None):
+        """grad = (S + sigma C z) / expected_batch_size.  In a process group every rank adds its
+        own N(0, (sigma C)^2 / world) share BEFORE the all-reduce, so the sum carries exactly
+        one N(0, (sigma C)^2).  `noise` injects z (tests)."""
+        grad = self._noise_scale_local(noise)
+        self.reduce_step()
+        return grad
+
+    # -- the step in three phases, so that a caller can capture the two compute phases into HIP
+    #    graphs and leave the collective between them as an ordinary RCCL call ------------------
+    @torch.no_grad()
+    def local_step(self, noise: Optional[torch.Tensor] = None):
+        """Per-rank work before the exchange: ghost norms, clip, clipped sums and -- unless the
+        fused single-GPU kernel will add it -- this rank's noise share and the scaling."""
+        self.clip_and_accumulate()
+        world, _ = self._world()
+        self._use_fused = self._fusable() or self._P is not None
+        if not (self._use_fused and world == 1):
+            self._noise_scale_local(noise)
+
+    @torch.no_grad()
+    def reduce_step(self):
+        """The one exchange of the step: sum all-reduce of the flat gradient bucket."""
+        import torch.distributed as dist
+        world, _ = self._world()
+        if world > 1:
+            dist.all_reduce(self._grad, op=dist.ReduceOp.SUM, group=self.process_group)
+
+    @torch.no_grad()
+    def apply_step(self, noise: Optional[torch.Tensor] = None):
+        """Parameter update from the (reduced) gradient."""
+        result = None
+        if self._use_fused:
+            self._fused_apply(noise)
+        else:
+            result = self.original_optimizer.step()
+        if self.accountant_hook is not None:
+            self.accountant_hook(self)
+        for t in self.module.tapes:  # a second step() without a new backward must fail loudly
+            t.g = None
+        return result
 
     def pre_step(self, noise: Optional[torch.Tensor] = None):
         self.clip_and_accumulate()
         self.add_noise_and_scale(noise)
-        if self.accountant_hook is not None:
-            self.accountant_hook(self)
 
     def step(self, closure=None):
-        if self._fusable() or self._P is not None:
-            self.clip_and_accumulate()
-            self._fused_step()
-            if self.accountant_hook is not None:
-                self.accountant_hook(self)
-            result = None
-        else:
-            self.pre_step()
-            result = self.original_optimizer.step()
-        for t in self.module.tapes:  # a second step() without a new backward must fail loudly
-            t.g = None
-        return result
+        self.local_step()
+        self.reduce_step()
+        return self.apply_step()
 
     def flat_noise_layout(self):
         """(name-less) list of (offset, numel, shape) per parameter in the flat buffers."""
