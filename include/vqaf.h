@@ -242,21 +242,24 @@ int vqaf_clip_coef(const float* sq, int B, float max_norm, float scale, float* c
  * per sample): same arithmetic as vqaf_ghost_sqnorm_linear / _affine accumulated over the layers
  * followed by vqaf_clip_coef.  The *_host arguments are HOST arrays of n_layers entries (device
  * pointers a[l], g[l]; in_dim / out_dim; kind 0 = Linear, 1 = Linear with bias, 2 = affine
- * normalisation with a = xhat, in_dim ignored).  n_layers <= 8.  norms, sq (B) may be NULL. */
+ * normalisation with a = xhat, in_dim ignored).  n_layers <= 8.  norms, sq (B) may be NULL.
+ * With scale_g_inplace != 0 every g[l] row is then multiplied by its sample's coef IN PLACE
+ * (g is not const in that mode); the clipped-sum entry points are then called with coef == NULL. */
 int vqaf_ghost_clip(int n_layers, const void* const* a_host, const void* const* g_host,
                     const int* in_dim_host, const int* out_dim_host, const int* kind_host, int B,
-                    int dtype, float max_norm, float scale, float* coef, float* norms, float* sq,
-                    vqaf_stream_t stream);
+                    int dtype, float max_norm, float scale, int scale_g_inplace, float* coef,
+                    float* norms, float* sq, vqaf_stream_t stream);
 
 /* Clipped gradient sum of a Linear:  SW (Out,In) f32 = sum_b coef[b] g_b a_b^T,
  * Sb (Out) f32 = sum_b coef[b] g_b (Sb may be NULL).  bf16 inputs use bf16 MFMA, f32
- * inputs the exact f32 MFMA.  accumulate != 0 adds into SW / Sb (micro-batching). */
+ * inputs the exact f32 MFMA.  accumulate != 0 adds into SW / Sb (micro-batching).
+ * coef == NULL means g is already scaled (vqaf_ghost_clip with scale_g_inplace). */
 int vqaf_clipped_sum_linear(const void* a, const void* g, const float* coef, int B, int In,
                             int Out, int dtype, int accumulate, float* SW, float* Sb,
                             vqaf_stream_t stream);
 
 /* Clipped gradient sums of an affine normalisation layer:
- * Sgamma[c] = sum_b coef[b] xhat[b,c] g[b,c];  Sbeta[c] = sum_b coef[b] g[b,c]. */
+ * Sgamma[c] = sum_b coef[b] xhat[b,c] g[b,c];  Sbeta[c] = sum_b coef[b] g[b,c]  (coef == NULL: 1). */
 int vqaf_clipped_sum_affine(const void* xhat, const void* g, const float* coef, int B, int C,
                             int dtype, int accumulate, float* Sgamma, float* Sbeta,
                             vqaf_stream_t stream);

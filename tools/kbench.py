@@ -15,10 +15,23 @@ from vqa_amd import ops  # noqa: E402
 from vqa_amd._lib import check, dtype_code, load, ptr, stream_ptr  # noqa: E402
 
 
+ISOLATED = False
+
+
 def timeit(fn, reps=30, warm=5):
     for i in range(warm):
         fn(i)
     torch.cuda.synchronize()
+    if ISOLATED:  # one launch at a time on an idle GPU: no overlap between consecutive launches
+        tot = 0.0
+        for i in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / reps
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(reps):
@@ -36,7 +49,10 @@ def main():
     ap.add_argument("--keep", type=float, default=0.5)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default="")
+    ap.add_argument("--isolated", action="store_true", help="synchronise between launches")
     a = ap.parse_args()
+    global ISOLATED
+    ISOLATED = a.isolated
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     s = 2 if a.dtype == "bf16" else 4

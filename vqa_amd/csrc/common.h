@@ -77,6 +77,26 @@ __device__ __forceinline__ void store8(void* base, size_t e, const float (&v)[8]
     p[0] = a; p[1] = b;
   }
 }
+// Streaming (non-temporal) stores for large outputs that nothing re-reads soon: they go to HBM
+// without displacing re-used data from the L2 / Infinity Cache and without leaving hundreds of
+// megabytes of dirty lines for the next kernel's reads to flush.
+__device__ __forceinline__ void store_nt16(void* p, u32x4 v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+}
+template <bool BF16>
+__device__ __forceinline__ void store8_nt(void* base, size_t e, const float (&v)[8]) {
+  if constexpr (BF16) {
+    u32x4 r;
+    r.x = pack_bf16x2(v[0], v[1]); r.y = pack_bf16x2(v[2], v[3]);
+    r.z = pack_bf16x2(v[4], v[5]); r.w = pack_bf16x2(v[6], v[7]);
+    store_nt16(reinterpret_cast<bf16_t*>(base) + e, r);
+  } else {
+    float* p = reinterpret_cast<float*>(base) + e;
+    store_nt16(p, u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
+    store_nt16(p + 4, u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])});
+  }
+}
+
 template <bool BF16>
 __device__ __forceinline__ float load1(const void* base, size_t e) {
   if constexpr (BF16) return bf16_to_f32(reinterpret_cast<const bf16_t*>(base)[e]);

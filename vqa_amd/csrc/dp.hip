@@ -79,9 +79,10 @@ struct GhostLayers {
 };
 template <bool BF16>
 __global__ void __launch_bounds__(DP_THREADS)
-ghost_clip_kernel(GhostLayers L, float max_norm, float scale, float* __restrict__ coef,
+ghost_clip_kernel(GhostLayers L, float max_norm, float scale, int scale_g, float* __restrict__ coef,
                   float* __restrict__ norms, float* __restrict__ sq_out) {
   __shared__ float red[DP_THREADS / 64];
+  __shared__ float s_coef;
   const int b = blockIdx.x;
   float total = 0.f;
   for (int l = 0; l < L.n; ++l) {
@@ -117,9 +118,22 @@ ghost_clip_kernel(GhostLayers L, float max_norm, float scale, float* __restrict_
   }
   if (threadIdx.x == 0) {
     const float n = scale * sqrtf(total);
-    coef[b] = scale * fminf(1.0f, max_norm / (n + 1e-6f));
+    const float c = scale * fminf(1.0f, max_norm / (n + 1e-6f));
+    coef[b] = c;
+    s_coef = c;
     if (norms != nullptr) norms[b] = n;
     if (sq_out != nullptr) sq_out[b] = total;
+  }
+  if (!scale_g) return;
+  // g_b <- coef_b * g_b for every layer, in place (the rows were just read, so they are cache
+  // hot): the clipped-sum kernels then run with coef == NULL, as plain batch contractions.
+  __syncthreads();
+  const float c = s_coef;
+  for (int l = 0; l < L.n; ++l) {
+    const int Out = L.out_dim[l];
+    void* gl = const_cast<void*>(L.g[l]);
+    for (int i = threadIdx.x; i < Out; i += DP_THREADS)
+      store1<BF16>(gl, (size_t)b * Out + i, c * load1<BF16>(gl, (size_t)b * Out + i));
   }
 }
 
@@ -159,7 +173,7 @@ clipped_sum_linear_kernel(const void* __restrict__ a, const void* __restrict__ g
       const int r = rg + 4 * i, bb = k0 + r;
       float gv = 0.f, av = 0.f;
       if (bb < B) {
-        if (m0 + col < Out) gv = coef[bb] * load1<BF16>(g, (size_t)bb * Out + m0 + col);
+        if (m0 + col < Out) gv = (coef != nullptr ? coef[bb] : 1.f) * load1<BF16>(g, (size_t)bb * Out + m0 + col);
         if (n0 + col < In) av = load1<BF16>(a, (size_t)bb * In + n0 + col);
       }
       Gs[r][col] = gv;
@@ -202,13 +216,15 @@ clipped_sum_linear_kernel(const void* __restrict__ a, const void* __restrict__ g
 // padded by 64 B so that the four k-rows of a transposed read fall on disjoint bank groups) and
 // the fragments are fetched with ds_read_b64_tr_b16, the hardware transposing read: a 16-lane
 // group reads a 4(k) x 16(column) block and each lane receives one column's four k values.
-// Workgroup tile 128 (Out) x 64 (In), four waves of 64 x 32 (2 x 1 MFMA tiles), 32 batch rows per
-// stage.  Staging goes through registers two stages ahead (loads of stage s+2 are in flight while
+// Workgroup tile 128 (Out) x 128 (In), four waves of 64 x 64 (2 x 2 MFMA tiles), 64 batch rows per
+// stage (16 MFMAs per wave and stage, so the staging overhead is amortised; LDS 80 KiB double
+// buffered, one workgroup per CU).  Staging goes through registers two stages ahead (loads of stage s+2 are in flight while
 // stage s is multiplied), the coefficient is applied while stage s+1 moves from registers to LDS
 // (the product is re-rounded to bf16 by v_cvt_pk_bf16_f32).
 constexpr int CB_TM = 128;
-constexpr int CB_TN = 64;
-constexpr int CB_KB = 32;
+constexpr int CB_TN = 128;
+constexpr int CB_KB = 64;
+constexpr int CB_PS = CB_KB / 16;   // 16-row passes per stage and operand
 constexpr int CB_PG = CB_TM + 32;  // LDS row pitch of the g tile (elements)
 constexpr int CB_PA = CB_TN + 32;  // LDS row pitch of the a tile
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -275,53 +291,67 @@ __global__ void __launch_bounds__(DP_THREADS)
 clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ g,
                                const float* __restrict__ coef, int B, int In, int Out,
                                int accumulate, float* __restrict__ SW, float* __restrict__ Sb) {
-  __shared__ __attribute__((aligned(16))) bf16_t ldg[2][CB_KB][CB_PG];
-  __shared__ __attribute__((aligned(16))) bf16_t lda[2][CB_KB][CB_PA];
+  extern __shared__ __attribute__((aligned(16))) bf16_t cb_lds[];
+  bf16_t (*ldg)[CB_KB][CB_PG] = reinterpret_cast<bf16_t (*)[CB_KB][CB_PG]>(cb_lds);
+  bf16_t (*lda)[CB_KB][CB_PA] = reinterpret_cast<bf16_t (*)[CB_KB][CB_PA]>(cb_lds + 2 * CB_KB * CB_PG);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * CB_TM, n0 = blockIdx.x * CB_TN;
-  const int gr = tid >> 4, gc = (tid & 15) * 8;  // g tile: rows gr, gr+16; 8 columns from gc
-  const int ar = tid >> 3, ac = (tid & 7) * 8;   // a tile: row ar; 8 columns from ac
+  const int gr = tid >> 4, gc = (tid & 15) * 8;  // rows gr + 16*ps, 8 columns from gc (both tiles)
   const bool do_bias = (Sb != nullptr) && (blockIdx.x == 0);
+  const bool interior = (m0 + CB_TM <= Out) && (n0 + CB_TN <= In);  // no column masking needed
   const int g16 = lane >> 4;
 
-  f32x16 acc[2];
+  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bsum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
   // two register sets; stage t lives in set t & 1
-  u32x4 rg[2][2], ra[2];
-  float rc[2][2];
+  u32x4 rg[2][CB_PS], ra[2][CB_PS];
+  float rc[2][CB_PS];
   const int stages = (B + CB_KB - 1) / CB_KB;
 
 #define CB_FETCH(SET, T)                                                              \
   do {                                                                                \
     const int k0_ = (T) * CB_KB;                                                      \
-    _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                \
+    _Pragma("unroll") for (int ps = 0; ps < CB_PS; ++ps) {                            \
       const int row = k0_ + gr + 16 * ps;                                             \
       rg[SET][ps] = load_row8<VEC_G>(g, row, B, m0 + gc, Out);                        \
-      rc[SET][ps] = coef[min(row, B - 1)];                                            \
+      ra[SET][ps] = load_row8<VEC_A>(a, row, B, n0 + gc, In);                         \
+      rc[SET][ps] = coef != nullptr ? coef[min(row, B - 1)] : 1.f;                    \
     }                                                                                 \
-    ra[SET] = load_row8<VEC_A>(a, k0_ + ar, B, n0 + ac, In);                          \
   } while (0)
 #define CB_STASH(SET, BUF, T)                                                         \
   do {                                                                                \
     const int k0_ = (T) * CB_KB;                                                      \
-    _Pragma("unroll") for (int ps = 0; ps < 2; ++ps) {                                \
+    _Pragma("unroll") for (int ps = 0; ps < CB_PS; ++ps) {                            \
+      const int row = k0_ + gr + 16 * ps;                                             \
       const float c = rc[SET][ps];                                                    \
-      u32x4 v = mask8(rg[SET][ps], k0_ + gr + 16 * ps, B, m0 + gc, Out);              \
-      v.x = scale_pack2(v.x, c, bsum[0], bsum[1]);                                    \
-      v.y = scale_pack2(v.y, c, bsum[2], bsum[3]);                                    \
-      v.z = scale_pack2(v.z, c, bsum[4], bsum[5]);                                    \
-      v.w = scale_pack2(v.w, c, bsum[6], bsum[7]);                                    \
+      u32x4 v = rg[SET][ps], w = ra[SET][ps];                                         \
+      if (!interior || k0_ + CB_KB > B) {                                             \
+        v = mask8(v, row, B, m0 + gc, Out);                                           \
+        w = mask8(w, row, B, n0 + gc, In);                                            \
+      }                                                                               \
+      if (coef != nullptr) {                                                          \
+        v.x = scale_pack2(v.x, c, bsum[0], bsum[1]);                                  \
+        v.y = scale_pack2(v.y, c, bsum[2], bsum[3]);                                  \
+        v.z = scale_pack2(v.z, c, bsum[4], bsum[5]);                                  \
+        v.w = scale_pack2(v.w, c, bsum[6], bsum[7]);                                  \
+      } else if (do_bias) {                                                           \
+        bsum[0] += bf16_lo(v.x); bsum[1] += bf16_hi(v.x); bsum[2] += bf16_lo(v.y);    \
+        bsum[3] += bf16_hi(v.y); bsum[4] += bf16_lo(v.z); bsum[5] += bf16_hi(v.z);    \
+        bsum[6] += bf16_lo(v.w); bsum[7] += bf16_hi(v.w);                             \
+      }                                                                               \
       *reinterpret_cast<u32x4*>(&ldg[BUF][gr + 16 * ps][gc]) = v;                     \
+      *reinterpret_cast<u32x4*>(&lda[BUF][gr + 16 * ps][gc]) = w;                     \
     }                                                                                 \
-    *reinterpret_cast<u32x4*>(&lda[BUF][ar][ac]) = mask8(ra[SET], k0_ + ar, B, n0 + ac, In); \
   } while (0)
 
   CB_FETCH(0, 0);
@@ -343,12 +373,17 @@ clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __res
 #pragma unroll
         for (int ks = 0; ks < CB_KB / 16; ++ks) {
           const int kblock = 16 * ks + 8 * (g16 >> 1);
-          const bf16x8 bfv = tr_frag<CB_PA>(ta, kblock, wn * 32 + 16 * (g16 & 1), lane);
+          bf16x8 afv[2], bfv[2];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const bf16x8 afv = tr_frag<CB_PG>(tg, kblock, wm * 64 + i * 32 + 16 * (g16 & 1), lane);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afv, bfv, acc[i], 0, 0, 0);
+            afv[i] = tr_frag<CB_PG>(tg, kblock, wm * 64 + i * 32 + 16 * (g16 & 1), lane);
+            bfv[i] = tr_frag<CB_PA>(ta, kblock, wn * 64 + i * 32 + 16 * (g16 & 1), lane);
           }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afv[i], bfv[j], acc[i][j], 0, 0, 0);
         }
         if (t + 1 < stages) CB_STASH(P ^ 1, P ^ 1, t + 1);
         __syncthreads();
@@ -360,16 +395,18 @@ clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __res
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int n = n0 + wn * 32 + (lane & 31);
-      if (m < Out && n < In) {
-        float* p = SW + (size_t)m * In + n;
-        *p = accumulate ? *p + acc[i][r] : acc[i][r];
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (m < Out && n < In) {
+          float* p = SW + (size_t)m * In + n;
+          *p = accumulate ? *p + acc[i][j][r] : acc[i][j][r];
+        }
       }
-    }
   if (do_bias) {
-    float* red = reinterpret_cast<float*>(&ldg[0][0][0]);  // 16 x 128 f32 = 8 KiB; the loop is done
+    float* red = reinterpret_cast<float*>(cb_lds);  // 16 x 128 f32 = 8 KiB; the loop is done
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[gr * CB_TM + gc + e] = bsum[e];
     __syncthreads();
@@ -408,7 +445,7 @@ clipped_sum_affine_kernel(const void* __restrict__ xhat, const void* __restrict_
         float gv[8], xv[8];
         load8<BF16>(g, (size_t)b * C + c0, gv);
         load8<BF16>(xhat, (size_t)b * C + c0, xv);
-        const float c = coef[b];
+        const float c = coef != nullptr ? coef[b] : 1.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float t = c * gv[e];
@@ -783,8 +820,8 @@ extern "C" int vqaf_clip_coef(const float* sq, int B, float max_norm, float scal
 
 extern "C" int vqaf_ghost_clip(int n_layers, const void* const* a_host, const void* const* g_host,
                                const int* in_dim_host, const int* out_dim_host, const int* kind_host,
-                               int B, int dtype, float max_norm, float scale, float* coef, float* norms,
-                               float* sq, vqaf_stream_t stream) {
+                               int B, int dtype, float max_norm, float scale, int scale_g_inplace,
+                               float* coef, float* norms, float* sq, vqaf_stream_t stream) {
   VQAF_ENTRY();
   VQAF_REQUIRE(a_host && g_host && in_dim_host && out_dim_host && kind_host && coef, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
@@ -806,10 +843,10 @@ extern "C" int vqaf_ghost_clip(int n_layers, const void* const* a_host, const vo
   }
   if (dtype == VQAF_BF16)
     hipLaunchKernelGGL(ghost_clip_kernel<true>, dim3(B), dim3(DP_THREADS), 0, (hipStream_t)stream, L,
-                       max_norm, scale, coef, norms, sq);
+                       max_norm, scale, scale_g_inplace, coef, norms, sq);
   else
     hipLaunchKernelGGL(ghost_clip_kernel<false>, dim3(B), dim3(DP_THREADS), 0, (hipStream_t)stream, L,
-                       max_norm, scale, coef, norms, sq);
+                       max_norm, scale, scale_g_inplace, coef, norms, sq);
   VQAF_LAUNCH_CHECK();
 }
 
@@ -817,7 +854,7 @@ extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float
                                        int In, int Out, int dtype, int accumulate, float* SW,
                                        float* Sb, vqaf_stream_t stream) {
   VQAF_ENTRY();
-  VQAF_REQUIRE(a && g && coef && SW, VQAF_E_NULL);
+  VQAF_REQUIRE(a && g && SW, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && In > 0 && Out > 0, VQAF_E_SHAPE);
   if (dtype == VQAF_BF16) {
@@ -832,9 +869,18 @@ extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float
     };
     const int vg = vec_of(g, Out), va = vec_of(a, In);
     hipStream_t st = (hipStream_t)stream;
-#define VQAF_CSB(VG, VA)                                                                         \
-  hipLaunchKernelGGL((clipped_sum_linear_bf16_kernel<VG, VA>), grid, dim3(DP_THREADS), 0, st, ab, \
-                     gb, coef, B, In, Out, accumulate, SW, Sb)
+    const size_t cb_smem = (size_t)2 * CB_KB * (CB_PG + CB_PA) * sizeof(bf16_t);  // 80 KiB
+#define VQAF_CSB(VG, VA)                                                                              \
+  do {                                                                                                \
+    static bool attr_set = false;                                                                     \
+    if (!attr_set) {                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clipped_sum_linear_bf16_kernel<VG, VA>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_smem);            \
+      attr_set = true;                                                                                \
+    }                                                                                                 \
+    hipLaunchKernelGGL((clipped_sum_linear_bf16_kernel<VG, VA>), grid, dim3(DP_THREADS), cb_smem, st, \
+                       ab, gb, coef, B, In, Out, accumulate, SW, Sb);                                 \
+  } while (0)
     if (vg == 8 && va == 8) VQAF_CSB(8, 8);
     else if (vg == 2 && va == 8) VQAF_CSB(2, 8);
     else if (vg == 8 && va == 2) VQAF_CSB(8, 2);
@@ -854,7 +900,7 @@ extern "C" int vqaf_clipped_sum_affine(const void* xhat, const void* g, const fl
                                        int C, int dtype, int accumulate, float* Sgamma,
                                        float* Sbeta, vqaf_stream_t stream) {
   VQAF_ENTRY();
-  VQAF_REQUIRE(xhat && g && coef, VQAF_E_NULL);
+  VQAF_REQUIRE(xhat && g, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && C > 0, VQAF_E_SHAPE);
   VQAF_REQUIRE(C % 8 == 0 && vqaf_aligned16(xhat) && vqaf_aligned16(g), VQAF_E_ALIGN);

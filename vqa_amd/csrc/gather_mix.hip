@@ -390,7 +390,7 @@ gather_mix_bwd_kernel(const void* __restrict__ grad_out, int ld_out, int col0,
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = (p == 0) ? gmix[i] : gsel[i] * (float)p;
-            store8<BF16>(grad_seq, seq_b + (size_t)n * D + d0, v);
+            store8_nt<BF16>(grad_seq, seq_b + (size_t)n * D + d0, v);
           }
         }
       }
@@ -410,7 +410,7 @@ gather_mix_bwd_kernel(const void* __restrict__ grad_out, int ld_out, int col0,
                 u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(grad_seq) +
                                                       (seq_b + (size_t)n * D + d0) * gsz);
 #pragma unroll
-                for (int w = 0; w < WG; ++w) dst[w] = cur[u][w];
+                for (int w = 0; w < WG; ++w) store_nt16(dst + w, cur[u][w]);
               } else {
                 float v[8];
                 if constexpr (BF16_G) {
@@ -424,7 +424,7 @@ gather_mix_bwd_kernel(const void* __restrict__ grad_out, int ld_out, int col0,
                   v[4] = __uint_as_float(cur[u][WG - 1].x); v[5] = __uint_as_float(cur[u][WG - 1].y);
                   v[6] = __uint_as_float(cur[u][WG - 1].z); v[7] = __uint_as_float(cur[u][WG - 1].w);
                 }
-                store8<BF16>(grad_seq, seq_b + (size_t)n * D + d0, v);
+                store8_nt<BF16>(grad_seq, seq_b + (size_t)n * D + d0, v);
               }
             }
           }
@@ -438,7 +438,7 @@ gather_mix_bwd_kernel(const void* __restrict__ grad_out, int ld_out, int col0,
       }
       // dropped rows: the broadcast mix gradient
       for (int n = g; n < N; n += ROWS)
-        if (pos[n] == NONE) store8<BF16>(grad_seq, seq_b + (size_t)n * D + d0, gmix);
+        if (pos[n] == NONE) store8_nt<BF16>(grad_seq, seq_b + (size_t)n * D + d0, gmix);
     }
   }
   if constexpr (!POOL) {

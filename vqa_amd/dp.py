@@ -393,6 +393,7 @@ class DPOptimizer:
         coef = torch.empty(B, dtype=torch.float32, device=dev)
         norms = torch.empty(B, dtype=torch.float32, device=dev)
         n = len(tapes)
+        prescaled = False
         same_dtype = all(t.g.dtype == tapes[0].g.dtype for t in tapes)
         if n <= 8 and same_dtype:
             import ctypes
@@ -402,9 +403,12 @@ class DPOptimizer:
             dout = (ctypes.c_int * n)(*[t.g.shape[1] for t in tapes])
             kind = (ctypes.c_int * n)(*[2 if t.kind != "linear" else int(t.module.bias is not None)
                                         for t in tapes])
+            # the same launch scales every recorded backprop row by its clip coefficient in place
+            # (the tapes are dead after this step), so the sums below are plain contractions
             check(lib.vqaf_ghost_clip(n, pa, pg, din, dout, kind, B, dtype_code(tapes[0].g),
-                                      self.max_grad_norm, scale, ptr(coef), ptr(norms), None, st),
+                                      self.max_grad_norm, scale, 1, ptr(coef), ptr(norms), None, st),
                   "vqaf_ghost_clip")
+            prescaled = True
         else:
             sq = torch.empty(B, dtype=torch.float32, device=dev)
             for i, t in enumerate(tapes):
@@ -425,14 +429,17 @@ class DPOptimizer:
             if t.kind == "linear":
                 sw = self._slice(S, m.weight)
                 sb = self._slice(S, m.bias) if m.bias is not None else None
-                check(lib.vqaf_clipped_sum_linear(ptr(a), ptr(g), ptr(coef), B, a.shape[1], g.shape[1],
+                check(lib.vqaf_clipped_sum_linear(ptr(a), ptr(g), None if prescaled else ptr(coef), B,
+                                                  a.shape[1], g.shape[1],
                                                   dtype_code(g), 0, ptr(sw), ptr(sb), st),
                       "vqaf_clipped_sum_linear")
             else:
-                check(lib.vqaf_clipped_sum_affine(ptr(a), ptr(g), ptr(coef), B, g.shape[1],
+                check(lib.vqaf_clipped_sum_affine(ptr(a), ptr(g), None if prescaled else ptr(coef), B, g.shape[1],
                                                   dtype_code(g), 0, ptr(self._slice(S, m.weight)),
                                                   ptr(self._slice(S, m.bias)), st),
                       "vqaf_clipped_sum_affine")
+        for t in tapes:  # the recorded backprops were scaled in place: they are spent
+            t.g = None
         return S
 
     @torch.no_grad()
