@@ -119,10 +119,12 @@ int vqaf_adv_swap_random(int64_t* top, const int64_t* bottom, int B, int K, int 
  * sample; weights and index lists stay in LDS in between.  Exactly one of `s` (B,N,H head scores)
  * and `w_in` (B,N weights) is given.  adv_mode: 0 = no swap, 1 = injected pos/src (B,k_adv),
  * 2 = in-kernel draws from rng_state.  w_out (B,N), bottom (B,N-K), pos_out/src_out may be NULL.
- * Same results as the separate entry points (same ranking, same draws for the same rng_state). */
+ * Same results as the separate entry points (same ranking, same draws for the same rng_state).
+ * `salt` is added to the seed: callers that select for several modalities from one rng_state give
+ * each its own salt and advance the counter once afterwards. */
 int vqaf_select(const float* s, const float* w_in, int B, int N, int H, int K, int adv_mode, int k_adv,
-                const int64_t* pos, const int64_t* src, const uint64_t* rng_state, float* w_out,
-                int64_t* top, int64_t* bottom, int64_t* pos_out, int64_t* src_out,
+                const int64_t* pos, const int64_t* src, const uint64_t* rng_state, uint64_t salt,
+                float* w_out, int64_t* top, int64_t* bottom, int64_t* pos_out, int64_t* src_out,
                 vqaf_stream_t stream);
 
 /* counter += delta on the device (stream-ordered; graph-capturable). */

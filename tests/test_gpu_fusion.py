@@ -469,6 +469,8 @@ def test_fused_select_equals_separate_kernels(dev):
         top_a = top_sep.clone()
         pos_a, src_a = ops.adv_swap_random_(top_a, bot_sep, k_adv, rng_a, record=True)
         r3 = ops.select_indices(K, weights=w_sep, k_adv=k_adv, rng=rng_b, want_bottom=True, record=True)
+        r3s = ops.select_indices(K, weights=w_sep, k_adv=k_adv, rng=ops.PhiloxState(dev, seed=5), record=True, salt=1)
+        assert not torch.equal(r3s["pos"], pos_a)  # another salt, another stream
         assert torch.equal(r3["pos"], pos_a) and torch.equal(r3["src"], src_a)
         assert torch.equal(r3["top"], top_a) and torch.equal(r3["bottom"], bot_sep)
         # injected swap

@@ -34,7 +34,8 @@ SIGNATURES = {
     "vqaf_topk": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_adv_swap": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vqaf_adv_swap_random": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
-    "vqaf_select": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vqaf_select": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_uint64, _P, _P, _P,
+                            _P, _P, _P]),
     "vqaf_rng_advance": (c_int, [_P, c_uint64, _P]),
     "vqaf_gather_mix": (c_int, [_P, _P, _P, c_int, c_float, _P, c_float, c_int, c_int, c_int,
                                 c_int, c_int, c_int, _P, _P]),

@@ -69,6 +69,9 @@ ghost_sqnorm_affine_kernel(const void* __restrict__ xhat, const void* __restrict
 //                   { sum (xhat g)^2 + sum g^2                   for an affine normalisation
 //   n = scale sqrt(sq);  coef = scale min(1, C / (n + 1e-6))
 constexpr int GC_MAX_LAYERS = 8;
+__device__ __forceinline__ bool vqaf_dev_aligned16(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
 struct GhostLayers {
   const void* a[GC_MAX_LAYERS];
   const void* g[GC_MAX_LAYERS];
@@ -103,13 +106,32 @@ ghost_clip_kernel(GhostLayers L, float max_norm, float scale, int scale_g, float
       total += block_sum(s, red);
     } else {
       float na = 0.f, ng = 0.f;
-      for (int i = threadIdx.x; i < In; i += DP_THREADS) {
-        const float v = load1<BF16>(L.a[l], (size_t)b * In + i);
-        na = fmaf(v, v, na);
+      // 16-byte loads where the row pitch keeps them aligned, element loads otherwise
+      if (In % 8 == 0 && vqaf_dev_aligned16(L.a[l])) {
+        for (int i = threadIdx.x * 8; i < In; i += DP_THREADS * 8) {
+          float v[8];
+          load8<BF16>(L.a[l], (size_t)b * In + i, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) na = fmaf(v[e], v[e], na);
+        }
+      } else {
+        for (int i = threadIdx.x; i < In; i += DP_THREADS) {
+          const float v = load1<BF16>(L.a[l], (size_t)b * In + i);
+          na = fmaf(v, v, na);
+        }
       }
-      for (int i = threadIdx.x; i < Out; i += DP_THREADS) {
-        const float v = load1<BF16>(L.g[l], (size_t)b * Out + i);
-        ng = fmaf(v, v, ng);
+      if (Out % 8 == 0 && vqaf_dev_aligned16(L.g[l])) {
+        for (int i = threadIdx.x * 8; i < Out; i += DP_THREADS * 8) {
+          float v[8];
+          load8<BF16>(L.g[l], (size_t)b * Out + i, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ng = fmaf(v[e], v[e], ng);
+        }
+      } else {
+        for (int i = threadIdx.x; i < Out; i += DP_THREADS) {
+          const float v = load1<BF16>(L.g[l], (size_t)b * Out + i);
+          ng = fmaf(v, v, ng);
+        }
       }
       na = block_sum(na, red);
       ng = block_sum(ng, red);

@@ -117,33 +117,38 @@ constexpr int SEL_MAX_H = 16;
 __global__ void select_kernel(const float* __restrict__ s, const float* __restrict__ w_in, int N, int H,
                               int K, int NP, int adv_mode, int k_adv, int NPK, int NPR,
                               const int64_t* __restrict__ pos, const int64_t* __restrict__ src,
-                              const uint64_t* __restrict__ rng_state, float* __restrict__ w_out,
-                              int64_t* __restrict__ top, int64_t* __restrict__ bottom,
-                              int64_t* __restrict__ pos_out, int64_t* __restrict__ src_out) {
+                              const uint64_t* __restrict__ rng_state, unsigned long long salt,
+                              float* __restrict__ w_out, int64_t* __restrict__ top,
+                              int64_t* __restrict__ bottom, int64_t* __restrict__ pos_out,
+                              int64_t* __restrict__ src_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [NP]
   int* rank = reinterpret_cast<int*>(keys + NP);                             // [N] full ranking
   int* s_pos = rank + N;                                                     // [k_adv]
   float* wl = reinterpret_cast<float*>(s_pos + (k_adv > 0 ? k_adv : 1));     // [N]
+  float* sl = wl + N;                                                        // [N*H] head scores
   __shared__ float stat[2][SEL_MAX_H];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   const int R = N - K;
 
   if (s != nullptr) {
+    // one coalesced sweep brings the sample's N x H scores into LDS; every later pass reads LDS
     const float* sb = s + (size_t)b * N * H;
+    for (int i = tid; i < N * H; i += nt) sl[i] = sb[i];
+    __syncthreads();
     for (int h = wave; h < H; h += nw) {  // a wave owns a head: no workgroup barrier inside
       float m = -INFINITY;
-      for (int n = lane; n < N; n += 64) m = fmaxf(m, sb[(size_t)n * H + h]);
+      for (int n = lane; n < N; n += 64) m = fmaxf(m, sl[n * H + h]);
       m = wave_max(m);
       float z = 0.f;
-      for (int n = lane; n < N; n += 64) z += expf(sb[(size_t)n * H + h] - m);
+      for (int n = lane; n < N; n += 64) z += expf(sl[n * H + h] - m);
       z = wave_sum(z);
       if (lane == 0) { stat[0][h] = m; stat[1][h] = z; }
     }
     __syncthreads();
     for (int n = tid; n < N; n += nt) {
       float a = 0.f;
-      for (int h = 0; h < H; ++h) a += expf(sb[(size_t)n * H + h] - stat[0][h]) / stat[1][h];
+      for (int h = 0; h < H; ++h) a += expf(sl[n * H + h] - stat[0][h]) / stat[1][h];
       wl[n] = a / (float)H;
     }
   } else {
@@ -171,10 +176,10 @@ __global__ void select_kernel(const float* __restrict__ s, const float* __restri
     __syncthreads();
   } else if (adv_mode == 2) {
     const unsigned long long seed = rng_state[0], counter = rng_state[1];
-    random_prefix(keys, K, NPK, seed, counter, 2ull * b);
+    random_prefix(keys, K, NPK, seed + salt, counter, 2ull * b);
     for (int j = tid; j < k_adv; j += nt) s_pos[j] = TK_MAX_N - 1 - (int)(keys[j] & (TK_MAX_N - 1));
     __syncthreads();
-    random_prefix(keys, R, NPR, seed, counter, 2ull * b + 1ull);
+    random_prefix(keys, R, NPR, seed + salt, counter, 2ull * b + 1ull);
     for (int j = tid; j < k_adv; j += nt) {
       const int p = s_pos[j];
       const int q = TK_MAX_N - 1 - (int)(keys[j] & (TK_MAX_N - 1));
@@ -244,8 +249,8 @@ extern "C" int vqaf_adv_swap_random(int64_t* top, const int64_t* bottom, int B, 
 
 extern "C" int vqaf_select(const float* s, const float* w_in, int B, int N, int H, int K, int adv_mode,
                            int k_adv, const int64_t* pos, const int64_t* src,
-                           const uint64_t* rng_state, float* w_out, int64_t* top, int64_t* bottom,
-                           int64_t* pos_out, int64_t* src_out, vqaf_stream_t stream) {
+                           const uint64_t* rng_state, uint64_t salt, float* w_out, int64_t* top,
+                           int64_t* bottom, int64_t* pos_out, int64_t* src_out, vqaf_stream_t stream) {
   VQAF_ENTRY();
   VQAF_REQUIRE((s != nullptr) != (w_in != nullptr), VQAF_E_NULL);  // exactly one source of weights
   VQAF_REQUIRE(top != nullptr, VQAF_E_NULL);
@@ -261,10 +266,14 @@ extern "C" int vqaf_select(const float* s, const float* w_in, int B, int N, int 
     k_adv = 0;
   }
   const int NP = next_pow2(N), NPK = next_pow2(K), NPR = next_pow2(R > 0 ? R : 1);
-  const size_t smem = (size_t)NP * 8 + (size_t)N * 4 + (size_t)(k_adv > 0 ? k_adv : 1) * 4 + (size_t)N * 4;
-  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(sort_threads(NP)), smem, (hipStream_t)stream, s, w_in,
-                     N, H, K, NP, adv_mode, k_adv, NPK, NPR, pos, src, rng_state, w_out, top, bottom,
-                     pos_out, src_out);
+  const size_t smem = (size_t)NP * 8 + (size_t)N * 4 + (size_t)(k_adv > 0 ? k_adv : 1) * 4 + (size_t)N * 4 +
+                      (s != nullptr ? (size_t)N * H * 4 : 0);
+  VQAF_REQUIRE(smem <= 64 * 1024, VQAF_E_SHAPE);
+  int threads = sort_threads(NP);
+  if (threads < 256) threads = 256;  // the score / weight passes want more lanes than the sort
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(threads), smem, (hipStream_t)stream, s, w_in, N, H, K,
+                     NP, adv_mode, k_adv, NPK, NPR, pos, src, rng_state, (unsigned long long)salt, w_out,
+                     top, bottom, pos_out, src_out);
   VQAF_LAUNCH_CHECK();
 }
 

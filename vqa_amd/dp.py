@@ -251,7 +251,12 @@ class DPOptimizer:
         self._P = self._M = self._V = self._shadow = self._step = None
         self._use_fused = False
         self.last_norms = None
-        self.last_clip = None
+        self._last_coef, self._last_scale = None, 1.0
+
+    @property
+    def last_clip(self):
+        """Per-sample clip factors min(1, C / (n_i + 1e-6)) of the last step (computed on demand)."""
+        return None if self._last_coef is None else self._last_coef / self._last_scale
 
     # -- torch.optim.Optimizer surface the training loop touches ------------------------------
     @property
@@ -317,7 +322,9 @@ class DPOptimizer:
             self._M = torch.zeros_like(self._P)
             self._V = torch.zeros_like(self._P)
             self._shadow = torch.zeros(self._numel, dtype=torch.bfloat16, device=device)
-            self._step = torch.zeros(2, dtype=torch.int64, device=device)
+            # {seed, updates applied}: the update count doubles as the counter of the noise stream,
+            # so one advance per step serves both the bias correction and the noise
+            self._step = ops.PhiloxState(device, seed=self._rng.seed, stream_salt=17).state
             lookup = {}
             with torch.no_grad():
                 for p in self.params:
@@ -351,13 +358,15 @@ class DPOptimizer:
             hi = max(self._offsets[id(p)] + (p.numel() + 3) // 4 * 4 for p in ps)
             b1, b2 = group["betas"]
             nz = noise[lo:hi] if noise is not None else None
-            check(lib.vqaf_dp_adamw(ptr(src[lo:hi]), ptr(nz), ptr(self._rng.state), std, scale,
+            single = len(self.original_optimizer.param_groups) == 1
+            noise_state = self._step if single else self._rng.state
+            check(lib.vqaf_dp_adamw(ptr(src[lo:hi]), ptr(nz), ptr(noise_state), std, scale,
                                     ptr(self._P[lo:hi]), ptr(self._M[lo:hi]), ptr(self._V[lo:hi]),
                                     ptr(self._shadow[lo:hi]), ptr(grad[lo:hi]), hi - lo, float(group["lr"]),
                                     float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                                     ptr(self._step), st), "vqaf_dp_adamw")
-            if world == 1 and nz is None and std != 0.0:
-                self._rng.advance()  # a fresh stream for the next group / step
+            if world == 1 and nz is None and std != 0.0 and not single:
+                self._rng.advance()  # several groups: a fresh stream for the next group / step
         check(lib.vqaf_rng_advance(ptr(self._step), 1, st), "vqaf_rng_advance")
 
     def _fused_step(self, noise: Optional[torch.Tensor] = None):
@@ -422,7 +431,7 @@ class DPOptimizer:
                                                        int(i > 0), ptr(sq), st), "vqaf_ghost_sqnorm_affine")
             check(lib.vqaf_clip_coef(ptr(sq), B, self.max_grad_norm, scale, ptr(coef), ptr(norms), st),
                   "vqaf_clip_coef")
-        self.last_norms, self.last_clip = norms, coef / scale
+        self.last_norms, self._last_coef, self._last_scale = norms, coef, scale
         for t in tapes:
             a, g = t.a, t.g.contiguous()
             m = t.module

@@ -43,13 +43,15 @@ class PrivacyAwareTokenPruning(nn.Module):
         self.noise_type = noise_type
         self.rng: Optional[ops.PhiloxState] = None  # None -> per-device default stream
         self.last_indices: Optional[torch.Tensor] = None
+        self._drew = False
 
     # -- index selection: utils/fusion.py:35-65 ------------------------------------------------
     @torch.no_grad()
     def select(self, attn_weights: Optional[torch.Tensor], n_tokens: int,
                replace_positions: Optional[torch.Tensor] = None,
                random_bottom: Optional[torch.Tensor] = None,
-               head_scores: Optional[torch.Tensor] = None) -> torch.Tensor:
+               head_scores: Optional[torch.Tensor] = None, salt: int = 0,
+               advance: bool = True) -> torch.Tensor:
         """Keep indices (B,K) int64, one kernel launch.  Give either `attn_weights` ((B,1,N) or
         (B,N), the module-boundary form) or raw `head_scores` (B,N,H) whose softmax / head mean is
         then fused into the same launch.  `replace_positions` / `random_bottom` (B,k_adv) inject
@@ -66,7 +68,9 @@ class PrivacyAwareTokenPruning(nn.Module):
             raise ValueError("inject both replace_positions and random_bottom, or neither")
         res = ops.select_indices(k, scores=head_scores, weights=attn_weights if head_scores is None else None,
                                  k_adv=k_adv, pos=replace_positions if k_adv else None,
-                                 src=random_bottom if k_adv else None, rng=self.rng)
+                                 src=random_bottom if k_adv else None, rng=self.rng, salt=salt,
+                                 advance=advance)
+        self._drew = res["drew"]  # True if the kernel consumed random numbers (caller may batch the advance)
         return res["top"]
 
     def _noise_args(self, noise: Optional[torch.Tensor]):
@@ -88,10 +92,11 @@ class PrivacyAwareTokenPruning(nn.Module):
                               noise_scale=float(self.noise_scale), rng=self.rng)
 
     def pool_spec(self, seq, attn_weights, replace_positions=None, random_bottom=None, noise=None,
-                  head_scores=None):
+                  head_scores=None, salt=0, advance=True):
         """Arguments for ops.pruned_pool: the same pruning, consumed as a token mean."""
         B, N, D = seq.shape
-        idx = self.select(attn_weights, N, replace_positions, random_bottom, head_scores=head_scores)
+        idx = self.select(attn_weights, N, replace_positions, random_bottom, head_scores=head_scores,
+                          salt=salt, advance=advance)
         self.last_indices = idx
         noise_t, noise_type = self._noise_args(noise)
         return dict(seq=seq, idx=idx, alpha=float(self.mixup_alpha), noise=noise_t,
@@ -179,10 +184,18 @@ class CoAttention(nn.Module):
         q_inject = q_inject or {}
         if self.use_pruning:
             if self.fuse_pool:
+                # both selections draw from the same counter with different salts; one advance after
                 v_hs = _head_scores(self.txt_to_vis_attn, q_global, v_seq)   # utils/fusion.py:234-238
-                v_spec = self.v_pruning.pool_spec(v_seq, None, head_scores=v_hs, **v_inject)
+                v_spec = self.v_pruning.pool_spec(v_seq, None, head_scores=v_hs, salt=0, advance=False,
+                                                  **v_inject)
                 q_hs = _head_scores(self.vis_to_txt_attn, v_global, q_seq)   # utils/fusion.py:243-247
-                q_spec = self.q_pruning.pool_spec(q_seq, None, head_scores=q_hs, **q_inject)
+                q_spec = self.q_pruning.pool_spec(q_seq, None, head_scores=q_hs, salt=1, advance=False,
+                                                  **q_inject)
+                rngs = {id(r): r for m, r in ((self.v_pruning, self.v_pruning.rng or ops.default_rng(v_seq.device)),
+                                              (self.q_pruning, self.q_pruning.rng or ops.default_rng(v_seq.device)))
+                        if m._drew}
+                for r in rngs.values():
+                    r.advance()
                 return ops.pruned_pool([v_spec, q_spec], v_seq.dtype)        # :253-254, :274
             v_w = _scores(self.txt_to_vis_attn, q_global, v_seq)
             v_pruned = self.v_pruning(v_seq, v_w, **v_inject)         # :240

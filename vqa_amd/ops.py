@@ -122,7 +122,8 @@ def head_score_matrix(q: torch.Tensor, seq: torch.Tensor, in_proj_weight: torch.
 def select_indices(k: int, *, scores: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None,
                    k_adv: int = 0, pos: Optional[torch.Tensor] = None, src: Optional[torch.Tensor] = None,
                    rng: Optional["PhiloxState"] = None, want_weights: bool = False,
-                   want_bottom: bool = False, record: bool = False) -> dict:
+                   want_bottom: bool = False, record: bool = False, salt: int = 0,
+                   advance: bool = True) -> dict:
     """Keep indices in one launch (vqaf_select): softmax/head-mean of `scores` (B,N,H) or given
     `weights` (B,N), ranking, and the adversarial swap -- injected (`pos`, `src`), drawn in the
     kernel (`rng`), or none (k_adv == 0)."""
@@ -155,10 +156,11 @@ def select_indices(k: int, *, scores: Optional[torch.Tensor] = None, weights: Op
         out["src"] = torch.empty(B, k_adv, dtype=torch.int64, device=dev)
     check(load().vqaf_select(ptr(scores), ptr(weights), B, N, H, k, mode, k_adv,
                              ptr(pos) if mode == 1 else None, ptr(src) if mode == 1 else None,
-                             ptr(rng.state) if mode == 2 else None, ptr(out["weights"]), ptr(out["top"]),
-                             ptr(out["bottom"]), ptr(out["pos"]), ptr(out["src"]), stream_ptr(dev)),
-          "vqaf_select")
-    if mode == 2:
+                             ptr(rng.state) if mode == 2 else None, int(salt), ptr(out["weights"]),
+                             ptr(out["top"]), ptr(out["bottom"]), ptr(out["pos"]), ptr(out["src"]),
+                             stream_ptr(dev)), "vqaf_select")
+    out["drew"] = mode == 2
+    if mode == 2 and advance:
         rng.advance()
     return out
 
