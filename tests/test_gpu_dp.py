@@ -322,3 +322,43 @@ def test_fused_adamw_step_matches_torch_adamw(dev):
     before = opt_f._P.clone()
     opt_f.step()
     assert not torch.equal(before, opt_f._P) and int(opt_f._step[1].item()) == 5
+
+
+def test_ghost_clip_equals_separate_kernels(dev):
+    """vqaf_ghost_clip (all layers + clip coefficient + in-place scaling in one launch) against
+    vqaf_ghost_sqnorm_linear/_affine + vqaf_clip_coef, f32 and bf16, vector and element paths."""
+    import ctypes
+    from vqa_amd._lib import check, dtype_code, load, ptr, stream_ptr
+    lib, st = load(), stream_ptr(dev)
+    B = 37
+    for dt in (torch.float32, torch.bfloat16):
+        layers = [("lin1", 1024, 2048), ("aff", 2048, 2048), ("lin0", 2048, 430), ("lin1", 66, 13)]
+        a = [gi.normal(10 + i, B, L[1]).to(dt).to(dev) for i, L in enumerate(layers)]
+        g = [(gi.normal(20 + i, B, L[2]) * 1e-2).to(dt).to(dev) for i, L in enumerate(layers)]
+        kinds = [1, 2, 0, 1]
+        sq = torch.empty(B, device=dev)
+        for i, (L, k) in enumerate(zip(layers, kinds)):
+            if k == 2:
+                check(lib.vqaf_ghost_sqnorm_affine(ptr(a[i]), ptr(g[i]), B, L[2], dtype_code(g[i]), int(i > 0),
+                                                   ptr(sq), st), "aff")
+            else:
+                check(lib.vqaf_ghost_sqnorm_linear(ptr(a[i]), ptr(g[i]), B, L[1], L[2], dtype_code(g[i]), k,
+                                                   int(i > 0), ptr(sq), st), "lin")
+        coef_ref, norm_ref = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        check(lib.vqaf_clip_coef(ptr(sq), B, 1.0, float(B), ptr(coef_ref), ptr(norm_ref), st), "clip")
+        n = len(layers)
+        g2 = [t.clone() for t in g]
+        pa = (ctypes.c_void_p * n)(*[ptr(t) for t in a])
+        pg = (ctypes.c_void_p * n)(*[ptr(t) for t in g2])
+        din = (ctypes.c_int * n)(*[L[1] for L in layers])
+        dout = (ctypes.c_int * n)(*[L[2] for L in layers])
+        kd = (ctypes.c_int * n)(*kinds)
+        coef, norms, sq2 = (torch.empty(B, device=dev) for _ in range(3))
+        check(lib.vqaf_ghost_clip(n, pa, pg, din, dout, kd, B, dtype_code(g[0]), 1.0, float(B), 1, ptr(coef),
+                                  ptr(norms), ptr(sq2), st), "ghost_clip")
+        np.testing.assert_allclose(sq2.cpu().numpy(), sq.cpu().numpy(), rtol=2e-6)
+        np.testing.assert_allclose(norms.cpu().numpy(), norm_ref.cpu().numpy(), rtol=2e-6)
+        np.testing.assert_allclose(coef.cpu().numpy(), coef_ref.cpu().numpy(), rtol=2e-6)
+        for i in range(n):  # rows scaled in place by their sample's coefficient
+            want = (g[i].float() * coef[:, None]).to(dt)
+            assert torch.equal(g2[i], want), i

@@ -122,10 +122,11 @@ __global__ void select_kernel(const float* __restrict__ s, const float* __restri
                               int64_t* __restrict__ bottom, int64_t* __restrict__ pos_out,
                               int64_t* __restrict__ src_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [NP]
-  int* rank = reinterpret_cast<int*>(keys + NP);                             // [N] full ranking
+  float* sl = reinterpret_cast<float*>(keys + NP);                           // [N*H] head scores (16-B aligned)
+  const int slots = (s != nullptr) ? ((N * H + 3) & ~3) : 0;
+  int* rank = reinterpret_cast<int*>(sl + slots);                            // [N] full ranking
   int* s_pos = rank + N;                                                     // [k_adv]
   float* wl = reinterpret_cast<float*>(s_pos + (k_adv > 0 ? k_adv : 1));     // [N]
-  float* sl = wl + N;                                                        // [N*H] head scores
   __shared__ float stat[2][SEL_MAX_H];
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
@@ -134,7 +135,13 @@ __global__ void select_kernel(const float* __restrict__ s, const float* __restri
   if (s != nullptr) {
     // one coalesced sweep brings the sample's N x H scores into LDS; every later pass reads LDS
     const float* sb = s + (size_t)b * N * H;
-    for (int i = tid; i < N * H; i += nt) sl[i] = sb[i];
+    if (((N * H) & 3) == 0) {  // rows of H floats: 16-byte loads whenever N*H is a multiple of 4
+      const f32x4* sb4 = reinterpret_cast<const f32x4*>(sb);
+      f32x4* sl4 = reinterpret_cast<f32x4*>(sl);
+      for (int i = tid; i < (N * H) >> 2; i += nt) sl4[i] = sb4[i];
+    } else {
+      for (int i = tid; i < N * H; i += nt) sl[i] = sb[i];
+    }
     __syncthreads();
     for (int h = wave; h < H; h += nw) {  // a wave owns a head: no workgroup barrier inside
       float m = -INFINITY;
@@ -267,7 +274,7 @@ extern "C" int vqaf_select(const float* s, const float* w_in, int B, int N, int 
   }
   const int NP = next_pow2(N), NPK = next_pow2(K), NPR = next_pow2(R > 0 ? R : 1);
   const size_t smem = (size_t)NP * 8 + (size_t)N * 4 + (size_t)(k_adv > 0 ? k_adv : 1) * 4 + (size_t)N * 4 +
-                      (s != nullptr ? (size_t)N * H * 4 : 0);
+                      (s != nullptr ? (size_t)((N * H + 3) & ~3) * 4 : 0);
   VQAF_REQUIRE(smem <= 64 * 1024, VQAF_E_SHAPE);
   int threads = sort_threads(NP);
   if (threads < 256) threads = 256;  // the score / weight passes want more lanes than the sort
