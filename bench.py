@@ -319,7 +319,7 @@ def main():
         lo, hi = vdist.shard_range(args.batch, rank, world)
         local_b, logical_b = hi - lo, args.batch
 
-    probe = Probe("gather_mix_pool:0")
+    probe = Probe("gather_mix_pool_multi")
     ops.PROBE = probe
     dt, launch, eager_ms = run_job(args, dev, dtype, rank, world, local_b, logical_b, probe)
     ops.PROBE = None
@@ -338,9 +338,10 @@ def main():
     if rank == 0:
         s = 2 if dtype == torch.bfloat16 else 4
         K = ops.keep_count(N_VIS, 1 - KEEP)
-        # algorithmic bytes of the pooled prune+mix launch on the vision tokens: every token row
-        # read once, the keep indices read, one pooled row written
-        alg_bytes = local_b * (N_VIS * D * s + K * 8 + D * s)
+        # algorithmic bytes of the pooled prune+mix launch (vision and text tokens in one launch):
+        # every token row read once, the keep indices read, one pooled row written per modality
+        Kt = ops.keep_count(N_TXT, 1 - KEEP)
+        alg_bytes = local_b * ((N_VIS * D * s + K * 8 + D * s) + (N_TXT * D * s + Kt * 8 + D * s))
         k_ms = probe.mean_ms()
         achieved = alg_bytes / k_ms / 1e6 if k_ms > 0 else 0.0
         traffic = None
@@ -348,7 +349,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
             if local_b == 1024 and args.dtype == "bf16":
-                traffic = pmc["kernels"]["gather_mix_kernel<true, true, 32, true>"]["hbm_bytes_per_launch"]
+                traffic = pmc["kernels"]["gather_mix_pool_multi_kernel<true, true, 32>"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
         line = {
@@ -366,7 +367,7 @@ def main():
                                    f"CoAttention pruning keep 0.5, {N_VIS} vision + {N_TXT} text tokens x {D}, "
                                    f"{C} classes; encoders bypassed",
                        "global_batch": logical_b, "per_gpu_batch": local_b, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": "gather_mix_kernel<pool> (vision tokens)",
+            "roofline": {"bound": "hbm", "kernel": "gather_mix_pool_multi_kernel (prune+mix, vision + text tokens)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(k_ms, 5), "algorithmic_bytes": alg_bytes},

@@ -179,6 +179,31 @@ int vqaf_gather_mix_pool_bwd(const void* grad_out, int ld_out, int col0, int g_d
                              const int64_t* idx, float alpha, int B, int N, int K, int D,
                              int dtype, void* grad_seq, vqaf_stream_t stream);
 
+/* Several modalities pooled by one launch (the vision and the text half of CoAttention's fused
+ * feature, utils/fusion.py:240-254, 274): same arithmetic as one vqaf_gather_mix_pool call per
+ * entry of `mods_host` (a HOST array of n_mod <= 4 descriptors; all modalities share B, D, dtype
+ * and the output (B, ld_out)).  The backward twin writes grad_seq of every modality whose
+ * pointer is non-NULL. */
+typedef struct vqaf_pool_mod {
+  const void* seq;           /* (B,N,D) */
+  const int64_t* idx;        /* (B,K)   */
+  const float* noise;        /* (B,K,D) f32 or NULL */
+  const uint64_t* rng_state; /* {seed, counter} or NULL */
+  float noise_scale, alpha;
+  int noise_kind, N, K, col0;
+} vqaf_pool_mod;
+typedef struct vqaf_pool_bwd_mod {
+  const int64_t* idx; /* (B,K) */
+  void* grad_seq;     /* (B,N,D) or NULL */
+  float alpha;
+  int N, K, col0;
+} vqaf_pool_bwd_mod;
+int vqaf_gather_mix_pool_multi(const vqaf_pool_mod* mods_host, int n_mod, int B, int D, int dtype,
+                               void* out, int ld_out, int out_dtype, vqaf_stream_t stream);
+int vqaf_gather_mix_pool_bwd_multi(const void* grad_out, int ld_out, int g_dtype,
+                                   const vqaf_pool_bwd_mod* mods_host, int n_mod, int B, int D,
+                                   int dtype, vqaf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Dense single-query cross-attention (non-pruning branch): the attention OUTPUT of
  * nn.MultiheadAttention(query=q[:,None], key=seq, value=seq), utils/fusion.py:257-268 and

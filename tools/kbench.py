@@ -86,6 +86,22 @@ def main():
     run("gather_mix_pool", B * (N * D * s + K * 8 + D * s),
         lambda i: check(lib.vqaf_gather_mix_pool(ptr(seqs[i % nbuf]), ptr(idx), None, 0, 0.0, None, 0.05, B, N, K, D,
                                                  dtype_code(seqs[0]), ptr(out), 2 * D, 0, dtype_code(out), st), "x"))
+    # both modalities of CoAttention in one launch (what the step uses)
+    import ctypes
+    from vqa_amd import _lib as L
+    Nt = 30
+    Kt = ops.keep_count(Nt, 1 - a.keep)
+    qseqs = [torch.randn(B, Nt, D, device=dev).to(dt) for _ in range(nbuf)]
+    qidx, _qb = ops.topk_indices(torch.rand(B, Nt, device=dev), Kt)
+    arrs = []
+    for i in range(nbuf):
+        arr = (L.PoolMod * 2)()
+        arr[0] = L.PoolMod(ptr(seqs[i]), ptr(idx), None, None, 0.0, 0.05, 0, N, K, 0)
+        arr[1] = L.PoolMod(ptr(qseqs[i]), ptr(qidx), None, None, 0.0, 0.05, 0, Nt, Kt, D)
+        arrs.append(arr)
+    run("gather_mix_pool_multi", B * ((N * D * s + K * 8 + D * s) + (Nt * D * s + Kt * 8 + D * s)),
+        lambda i: check(lib.vqaf_gather_mix_pool_multi(ctypes.cast(arrs[i % nbuf], ctypes.c_void_p), 2, B, D,
+                                                       dtype_code(seqs[0]), ptr(out), 2 * D, dtype_code(out), st), "x"))
     gouts = [torch.randn(B, 2 * D, device=dev).to(dt) for _ in range(2)]
     gseqs = [torch.empty(B, N, D, dtype=dt, device=dev) for _ in range(nbuf)]
     run("gather_mix_pool_bwd", B * (N * D * s + K * 8 + D * s),

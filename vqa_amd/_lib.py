@@ -21,6 +21,20 @@ NOISE_NONE, NOISE_GAUSSIAN, NOISE_UNIFORM = 0, 1, 2
 
 _P = c_void_p
 
+
+class PoolMod(ctypes.Structure):
+    """vqaf_pool_mod of include/vqaf.h."""
+    _fields_ = [("seq", c_void_p), ("idx", c_void_p), ("noise", c_void_p), ("rng_state", c_void_p),
+                ("noise_scale", c_float), ("alpha", c_float), ("noise_kind", c_int), ("N", c_int),
+                ("K", c_int), ("col0", c_int)]
+
+
+class PoolBwdMod(ctypes.Structure):
+    """vqaf_pool_bwd_mod of include/vqaf.h."""
+    _fields_ = [("idx", c_void_p), ("grad_seq", c_void_p), ("alpha", c_float), ("N", c_int), ("K", c_int),
+                ("col0", c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/vqaf.h one to one.
 SIGNATURES = {
     "vqaf_version": (c_int, []),
@@ -51,6 +65,8 @@ SIGNATURES = {
     "vqaf_softmax_heads_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "vqaf_weighted_token_sum": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "vqaf_token_outer": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vqaf_gather_mix_pool_multi": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "vqaf_gather_mix_pool_bwd_multi": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "vqaf_gemm_f32": (c_int, [_P, c_int, c_long, c_long, c_long, _P, c_int, c_long, c_long, c_long,
                               _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
                               c_float, c_int, _P]),

@@ -285,55 +285,84 @@ def mean_pool(x: torch.Tensor) -> torch.Tensor:
 class _PrunedPool(torch.autograd.Function):
     """fused[:, off:off+D] = mean_j prune(seq_m, idx_m)[:, j, :] for each modality m, without
     writing the pruned token tensors.  Inputs: a list of (seq, idx, alpha, noise, kind, scale,
-    rng_state) flattened; output (B, sum D_m)."""
+    rng_state) flattened; output (B, sum D_m).  Modalities that share dtype and width (the vision
+    and text halves of CoAttention) go through ONE launch forward and ONE backward."""
 
     @staticmethod
     def forward(ctx, n_mod, out_dtype, *flat):
+        import ctypes
         mods = [flat[i * 7:(i + 1) * 7] for i in range(n_mod)]
         B = mods[0][0].shape[0]
         dev = mods[0][0].device
         widths = [m[0].shape[2] for m in mods]
         ld = sum(widths)
         out = torch.empty(B, ld, dtype=out_dtype, device=dev)
-        lib = load()
+        lib, st = load(), stream_ptr(dev)
         col0 = 0
-        saved, metas = [], []
+        saved, metas, keep = [], [], []
         for (seq, idx, alpha, noise, kind, scale, state), D in zip(mods, widths):
-            _, N, _ = seq.shape
-            K = idx.shape[1]
             seq_c, idx_c = seq.contiguous(), idx.contiguous()
             noise_c = noise.to(torch.float32).contiguous() if noise is not None else None
-            _probe(f"gather_mix_pool:{len(saved)}", "begin")
-            check(lib.vqaf_gather_mix_pool(ptr(seq_c), ptr(idx_c), ptr(noise_c), kind, float(scale),
-                                           ptr(state), float(alpha), B, N, K, D, dtype_code(seq_c),
-                                           ptr(out), ld, col0, dtype_code(out), stream_ptr(dev)),
-                  "vqaf_gather_mix_pool")
-            _probe(f"gather_mix_pool:{len(saved)}", "end")
-            if state is not None:  # next consumer gets a fresh stream
-                check(lib.vqaf_rng_advance(ptr(state), 1, stream_ptr(dev)), "vqaf_rng_advance")
+            keep.append((seq_c, idx_c, noise_c, state, float(alpha), int(kind), float(scale)))
             saved.append(idx_c)
-            metas.append((N, K, D, float(alpha), seq.dtype, col0))
+            metas.append((seq.shape[1], idx.shape[1], D, float(alpha), seq.dtype, col0))
             col0 += D
+        uniform = n_mod > 1 and n_mod <= 4 and len(set(widths)) == 1 and len({m[0].dtype for m in mods}) == 1
+        if uniform:
+            arr = (_lib.PoolMod * n_mod)()
+            for i, ((seq_c, idx_c, noise_c, state, alpha, kind, scale), meta) in enumerate(zip(keep, metas)):
+                arr[i] = _lib.PoolMod(ptr(seq_c), ptr(idx_c), ptr(noise_c), ptr(state), scale, alpha, kind,
+                                      meta[0], meta[1], meta[5])
+            _probe("gather_mix_pool_multi", "begin")
+            check(lib.vqaf_gather_mix_pool_multi(ctypes.cast(arr, ctypes.c_void_p), n_mod, B, widths[0],
+                                                 dtype_code(keep[0][0]), ptr(out), ld, dtype_code(out), st),
+                  "vqaf_gather_mix_pool_multi")
+            _probe("gather_mix_pool_multi", "end")
+        else:
+            for i, ((seq_c, idx_c, noise_c, state, alpha, kind, scale), (N, K, D, _a, _dt, c0)) in \
+                    enumerate(zip(keep, metas)):
+                _probe(f"gather_mix_pool:{i}", "begin")
+                check(lib.vqaf_gather_mix_pool(ptr(seq_c), ptr(idx_c), ptr(noise_c), kind, scale, ptr(state),
+                                               alpha, B, N, K, D, dtype_code(seq_c), ptr(out), ld, c0,
+                                               dtype_code(out), st), "vqaf_gather_mix_pool")
+                _probe(f"gather_mix_pool:{i}", "end")
+        for (_s, _i, _n, state, _al, kind, _sc) in keep:
+            if state is not None and kind != _lib.NOISE_NONE:  # next consumer gets a fresh stream
+                check(lib.vqaf_rng_advance(ptr(state), 1, st), "vqaf_rng_advance")
         ctx.save_for_backward(*saved)
         ctx.metas = metas
-        ctx.B, ctx.ld, ctx.n_mod = B, ld, n_mod
+        ctx.B, ctx.ld, ctx.n_mod, ctx.uniform = B, ld, n_mod, uniform
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
+        import ctypes
         g = grad_out.contiguous()
         if g.dtype not in (torch.float32, torch.bfloat16):
             g = g.float()
-        lib = load()
+        lib, st = load(), stream_ptr(g.device)
         grads = [None, None]
-        for i, (idx_c, (N, K, D, alpha, sdt, col0)) in enumerate(zip(ctx.saved_tensors, ctx.metas)):
-            gs = None
-            if ctx.needs_input_grad[2 + 7 * i]:
-                gs = torch.empty(ctx.B, N, D, dtype=sdt, device=g.device)
-                check(lib.vqaf_gather_mix_pool_bwd(ptr(g), ctx.ld, col0, dtype_code(g), ptr(idx_c),
-                                                   alpha, ctx.B, N, K, D, dtype_code(gs), ptr(gs),
-                                                   stream_ptr(g.device)), "vqaf_gather_mix_pool_bwd")
-            grads.extend([gs, None, None, None, None, None, None])
+        outs = []
+        for i, (N, K, D, alpha, sdt, col0) in enumerate(ctx.metas):
+            need = ctx.needs_input_grad[2 + 7 * i]
+            outs.append(torch.empty(ctx.B, N, D, dtype=sdt, device=g.device) if need else None)
+        if ctx.uniform and any(o is not None for o in outs):
+            arr = (_lib.PoolBwdMod * ctx.n_mod)()
+            for i, (idx_c, (N, K, D, alpha, sdt, col0)) in enumerate(zip(ctx.saved_tensors, ctx.metas)):
+                arr[i] = _lib.PoolBwdMod(ptr(idx_c), ptr(outs[i]), alpha, N, K, col0)
+            sdt0 = ctx.metas[0][4]
+            check(lib.vqaf_gather_mix_pool_bwd_multi(ptr(g), ctx.ld, dtype_code(g), ctypes.cast(arr, ctypes.c_void_p),
+                                                     ctx.n_mod, ctx.B, ctx.metas[0][2],
+                                                     _lib.BF16 if sdt0 == torch.bfloat16 else _lib.F32, st),
+                  "vqaf_gather_mix_pool_bwd_multi")
+        else:
+            for i, (idx_c, (N, K, D, alpha, sdt, col0)) in enumerate(zip(ctx.saved_tensors, ctx.metas)):
+                if outs[i] is not None:
+                    check(lib.vqaf_gather_mix_pool_bwd(ptr(g), ctx.ld, col0, dtype_code(g), ptr(idx_c), alpha,
+                                                       ctx.B, N, K, D, dtype_code(outs[i]), ptr(outs[i]), st),
+                          "vqaf_gather_mix_pool_bwd")
+        for o in outs:
+            grads.extend([o, None, None, None, None, None, None])
         return tuple(grads)
 
 
