@@ -1,0 +1,83 @@
+"""Training / validation loops with the call order of the reference (utils/src.py:24-126, 129-245)
+and no per-batch host synchronisation.
+
+The reference calls `.item()` three times per training step (utils/src.py:109-111) and copies
+predictions to the host every validation batch; here loss and accuracy are accumulated on the
+device and copied once per epoch.  Signatures follow the reference (`train(model, train_loader,
+optimizer, criterion, device, model_type, use_dp_sgd, lambda_ib)`; `optimizer` is a torch
+optimizer or the dict {'main': ..., 'classifier': DPOptimizer} that train.py:162 builds).
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+
+
+def _batch(batch, device):
+    inputs = batch['inputs']
+    return (batch['image'].to(device), inputs['input_ids'].to(device), inputs['attention_mask'].to(device),
+            batch['answer'].to(device))
+
+
+def train(model: nn.Module, train_loader, optimizer, criterion, device, model_type: str = "VQAModel",
+          use_dp_sgd: bool = False, lambda_ib: float = 0.01) -> Tuple[float, float]:
+    """One epoch; returns (average loss, accuracy in %) like utils/src.py:123-126."""
+    if model_type == "VQAModel_IB":
+        raise NotImplementedError("VQAModel_IB is outside the accelerated path")
+    model.train()
+    split = isinstance(optimizer, dict)
+    tot_loss = torch.zeros((), dtype=torch.float64, device=device)
+    tot_correct = torch.zeros((), dtype=torch.int64, device=device)
+    n = 0
+    for batch in train_loader:
+        if batch is None:  # an empty Poisson-sampled batch
+            continue
+        images, ids, mask, answers = _batch(batch, device)
+        if split:                                   # utils/src.py:66-70
+            optimizer['main'].zero_grad()
+            optimizer['classifier'].zero_grad()
+        else:
+            optimizer.zero_grad()
+        outputs = model(images=images, input_ids=ids, attention_mask=mask)   # :91-95
+        loss = criterion(outputs, answers)                                   # :96
+        loss.backward()                                                      # :99
+        if split:                                                            # :102-106
+            optimizer['main'].step()
+            optimizer['classifier'].step()
+        else:
+            optimizer.step()
+        b = images.size(0)
+        tot_loss += loss.detach().double() * b                              # :109 without .item()
+        tot_correct += (outputs.detach().argmax(dim=1) == answers).sum()    # :110
+        n += b
+    if n == 0:
+        return 0.0, 0.0
+    return float(tot_loss.item() / n), float(tot_correct.item() / n * 100.0)
+
+
+@torch.no_grad()
+def validate(model: nn.Module, val_loader, criterion, device, model_type: str = "VQAModel",
+             mode: str = "val") -> Tuple[float, float, Dict[str, torch.Tensor]]:
+    """Returns (average loss, accuracy in %, {'preds': ..., 'labels': ...}); the reference's
+    sklearn / seaborn reporting (utils/src.py:183-243) is left to the caller."""
+    model.eval()
+    tot_loss = torch.zeros((), dtype=torch.float64, device=device)
+    preds, labels = [], []
+    n = 0
+    for batch in val_loader:
+        if batch is None:
+            continue
+        images, ids, mask, answers = _batch(batch, device)
+        out = model(images=images, input_ids=ids, attention_mask=mask)
+        out = out[0] if isinstance(out, tuple) else out
+        tot_loss += criterion(out, answers).double() * images.size(0)
+        preds.append(out.argmax(dim=1))
+        labels.append(answers)
+        n += images.size(0)
+    if n == 0:
+        return 0.0, 0.0, {"preds": torch.empty(0), "labels": torch.empty(0)}
+    p, l = torch.cat(preds), torch.cat(labels)
+    acc = float((p == l).sum().item() / n * 100.0)
+    return float(tot_loss.item() / n), acc, {"preds": p.cpu(), "labels": l.cpu()}
