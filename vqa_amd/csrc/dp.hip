@@ -380,36 +380,34 @@ clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __res
   CB_FETCH(1, 1);
   CB_STASH(0, 0, 0);
   __syncthreads();
+  // Branch-free loop body (an odd stage count is padded with one all-zero stage: rows past the
+  // batch are clamped on load and masked on the way to LDS), so the waits stay counted.
+  const int stages2 = (stages + 1) & ~1;
 #pragma unroll 1
-  for (int s = 0; s < stages; s += 2) {
+  for (int s = 0; s < stages2; s += 2) {
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
       const int t = s + P;
-      if (t < stages) {
-        // set P is free (stage t already sits in LDS).  The prefetch is unconditional -- past the
-        // last stage it re-reads clamped rows that nobody consumes -- because a conditional load
-        // would force the compiler to wait for ALL outstanding loads at the next use.
-        CB_FETCH(P, t + 2);
-        const bf16_t* tg = &ldg[P][0][0];
-        const bf16_t* ta = &lda[P][0][0];
+      CB_FETCH(P, t + 2);  // set P is free: stage t already sits in LDS
+      const bf16_t* tg = &ldg[P][0][0];
+      const bf16_t* ta = &lda[P][0][0];
 #pragma unroll
-        for (int ks = 0; ks < CB_KB / 16; ++ks) {
-          const int kblock = 16 * ks + 8 * (g16 >> 1);
-          bf16x8 afv[2], bfv[2];
+      for (int ks = 0; ks < CB_KB / 16; ++ks) {
+        const int kblock = 16 * ks + 8 * (g16 >> 1);
+        bf16x8 afv[2], bfv[2];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            afv[i] = tr_frag<CB_PG>(tg, kblock, wm * 64 + i * 32 + 16 * (g16 & 1), lane);
-            bfv[i] = tr_frag<CB_PA>(ta, kblock, wn * 64 + i * 32 + 16 * (g16 & 1), lane);
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afv[i], bfv[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+          afv[i] = tr_frag<CB_PG>(tg, kblock, wm * 64 + i * 32 + 16 * (g16 & 1), lane);
+          bfv[i] = tr_frag<CB_PA>(ta, kblock, wn * 64 + i * 32 + 16 * (g16 & 1), lane);
         }
-        if (t + 1 < stages) CB_STASH(P ^ 1, P ^ 1, t + 1);
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afv[i], bfv[j], acc[i][j], 0, 0, 0);
       }
+      CB_STASH(P ^ 1, P ^ 1, t + 1);
+      __syncthreads();
     }
   }
 #undef CB_FETCH

@@ -127,28 +127,26 @@ gemm_f32_kernel(const void* __restrict__ A, long a_sg, long a_sm, long a_sk,
   store_tile<AMODE, A_BF16>(As[0], tid, ra[0], m0, M, 0, K);
   store_tile<BMODE, B_BF16>(Bs[0], tid, rb[0], n0, N, 0, K);
   __syncthreads();
+  // The loop body is branch-free (an odd stage count is padded with one all-zero stage: indices
+  // are clamped on load and masked to zero on store), so every wait the compiler inserts is a
+  // counted one and the loads of two stages really stay in flight.
+  const int stages2 = (stages + 1) & ~1;
 #pragma unroll 1
-  for (int s = 0; s < stages; s += 2) {
+  for (int s = 0; s < stages2; s += 2) {
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
       const int t = s + P;
-      if (t < stages) {
-        // set P is free (stage t already sits in LDS); the prefetch is unconditional (indices are
-        // clamped, surplus stages are never consumed) so that the waits below stay counted
-        fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, (t + 2) * GK, K, tid, ra[P]);
-        fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, (t + 2) * GK, K, tid, rb[P]);
+      fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, (t + 2) * GK, K, tid, ra[P]);
+      fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, (t + 2) * GK, K, tid, rb[P]);
 #pragma unroll
-        for (int kk = 0; kk < GK; kk += 2) {
-          const float af = As[P][kk + (lane >> 5)][wm * 32 + (lane & 31)];
-          const float bf = Bs[P][kk + (lane >> 5)][wn * 32 + (lane & 31)];
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
-        }
-        if (t + 1 < stages) {
-          store_tile<AMODE, A_BF16>(As[P ^ 1], tid, ra[P ^ 1], m0, M, (t + 1) * GK, K);
-          store_tile<BMODE, B_BF16>(Bs[P ^ 1], tid, rb[P ^ 1], n0, N, (t + 1) * GK, K);
-        }
-        __syncthreads();
+      for (int kk = 0; kk < GK; kk += 2) {
+        const float af = As[P][kk + (lane >> 5)][wm * 32 + (lane & 31)];
+        const float bf = Bs[P][kk + (lane >> 5)][wn * 32 + (lane & 31)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
       }
+      store_tile<AMODE, A_BF16>(As[P ^ 1], tid, ra[P ^ 1], m0, M, (t + 1) * GK, K);
+      store_tile<BMODE, B_BF16>(Bs[P ^ 1], tid, rb[P ^ 1], n0, N, (t + 1) * GK, K);
+      __syncthreads();
     }
   }
   // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
