@@ -596,10 +596,13 @@ dp_adamw_kernel(const float* __restrict__ S, const float* __restrict__ noise,
       pv[j] -= step_size * (mv[j] / denom);
     }
     if (cnt == 4) {
-      *reinterpret_cast<f32x4*>(param + i0) = f32x4{pv[0], pv[1], pv[2], pv[3]};
-      *reinterpret_cast<f32x4*>(exp_avg + i0) = f32x4{mv[0], mv[1], mv[2], mv[3]};
-      *reinterpret_cast<f32x4*>(exp_avg_sq + i0) = f32x4{vv[0], vv[1], vv[2], vv[3]};
-      if (grad_out != nullptr) *reinterpret_cast<f32x4*>(grad_out + i0) = f32x4{gv[0], gv[1], gv[2], gv[3]};
+      // parameters, moments and gradient are next touched one whole step later: streaming stores
+      // keep them from displacing (and dirtying) the caches the next forward reads through
+      store_nt16(param + i0, u32x4{__float_as_uint(pv[0]), __float_as_uint(pv[1]), __float_as_uint(pv[2]), __float_as_uint(pv[3])});
+      store_nt16(exp_avg + i0, u32x4{__float_as_uint(mv[0]), __float_as_uint(mv[1]), __float_as_uint(mv[2]), __float_as_uint(mv[3])});
+      store_nt16(exp_avg_sq + i0, u32x4{__float_as_uint(vv[0]), __float_as_uint(vv[1]), __float_as_uint(vv[2]), __float_as_uint(vv[3])});
+      if (grad_out != nullptr)
+        store_nt16(grad_out + i0, u32x4{__float_as_uint(gv[0]), __float_as_uint(gv[1]), __float_as_uint(gv[2]), __float_as_uint(gv[3])});
       if (shadow != nullptr)
         *reinterpret_cast<u32x2*>(shadow + i0) = u32x2{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
     } else {
