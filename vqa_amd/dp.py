@@ -26,7 +26,7 @@ exactly once.
 from __future__ import annotations
 
 import math
-from typing import Iterable, List, Optional
+from typing import List, Optional
 
 import torch
 import torch.nn as nn
@@ -316,7 +316,9 @@ class DPOptimizer:
         return all(p.dtype == torch.float32 for p in self.params) and len(opt.state) == 0
 
     def _fused_buffers(self, device):
-        """Flat parameter / moment buckets; every Parameter becomes a view of the flat bucket."""
+        """Flat parameter / moment buckets; every Parameter becomes a view of the flat bucket
+        (so move the module to its device BEFORE the first step; a later .to() would detach the
+        parameters from the bucket)."""
         if self._P is None:
             self._P = torch.zeros(self._numel, dtype=torch.float32, device=device)
             self._M = torch.zeros_like(self._P)

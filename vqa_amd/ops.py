@@ -6,7 +6,6 @@ device memory, streams and autograd bookkeeping only; the arithmetic is in the k
 """
 from __future__ import annotations
 
-import math
 from typing import Optional, Tuple
 
 import torch
@@ -429,7 +428,3 @@ def keep_count(n_tokens: int, prune_ratio: float) -> int:
 def adv_count(k: int, adv_ratio: float) -> int:
     """k_adv = max(1, int(k * adv_ratio)) (utils/fusion.py:54)."""
     return max(1, int(k * adv_ratio))
-
-
-def sqrt_dh(embed_dim: int, num_heads: int) -> float:
-    return math.sqrt(embed_dim // num_heads)
