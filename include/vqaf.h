@@ -68,12 +68,34 @@ int vqaf_fold_query(const void* q, const void* in_proj_weight, const void* in_pr
                     int B, int D, int H, int dtype, int w_dtype, float* qproj_ws, float* u,
                     vqaf_stream_t stream);
 
+/* vqaf_fold_query for n <= 4 (query, in_proj) pairs of one shape in two launches instead of 2n
+ * (CoAttention folds its text->vision and vision->text queries together). */
+typedef struct vqaf_fold_desc {
+  const void* q;              /* (B,D) `dtype` */
+  const void* in_proj_weight; /* (3D,D) `w_dtype` */
+  const void* in_proj_bias;   /* (3D) `w_dtype` */
+  float* qproj_ws;            /* (B,D) f32 workspace */
+  float* u;                   /* (B,H,D) f32 out */
+} vqaf_fold_desc;
+int vqaf_fold_query_multi(const vqaf_fold_desc* descs_host, int n, int B, int D, int H, int dtype,
+                          int w_dtype, vqaf_stream_t stream);
+
 /* s (B,N,H) f32  <-  seq (B,N,D) `dtype`, u (B,H,D) f32.  Raw per-head scaled scores.
  * With bf16 tokens, H <= 8 and D in {64,128,256,512,768,1024} the products run on bf16 MFMA:
  * tokens are exact, u enters as two bf16 terms bf16(u) + bf16(u - bf16(u)) (accurate to ~2^-17);
  * otherwise on the f32 vector ALU. */
 int vqaf_head_scores(const void* seq, const float* u, int B, int N, int D, int H, int dtype,
                      float* s, vqaf_stream_t stream);
+
+/* vqaf_head_scores for n <= 4 token sets (same B, D, H, dtype; different N) in one launch. */
+typedef struct vqaf_scores_desc {
+  const void* seq; /* (B,N,D) */
+  const float* u;  /* (B,H,D) */
+  float* s;        /* (B,N,H) out */
+  int N;
+} vqaf_scores_desc;
+int vqaf_head_scores_multi(const vqaf_scores_desc* descs_host, int n, int B, int D, int H, int dtype,
+                           vqaf_stream_t stream);
 
 /* w (B,N) f32  <-  s (B,N,H) f32: softmax over n per head, then mean over heads. */
 int vqaf_attn_weights(const float* s, int B, int N, int H, float* w, vqaf_stream_t stream);
@@ -126,6 +148,24 @@ int vqaf_select(const float* s, const float* w_in, int B, int N, int H, int K, i
                 const int64_t* pos, const int64_t* src, const uint64_t* rng_state, uint64_t salt,
                 float* w_out, int64_t* top, int64_t* bottom, int64_t* pos_out, int64_t* src_out,
                 vqaf_stream_t stream);
+
+/* vqaf_select for n <= 4 modalities (same B, H and rng_state; per-modality fields as the arguments
+ * of vqaf_select) in one launch. */
+typedef struct vqaf_select_desc {
+  const float* s;
+  const float* w_in;
+  const int64_t* pos;
+  const int64_t* src;
+  float* w_out;
+  int64_t* top;
+  int64_t* bottom;
+  int64_t* pos_out;
+  int64_t* src_out;
+  uint64_t salt;
+  int N, K, adv_mode, k_adv;
+} vqaf_select_desc;
+int vqaf_select_multi(const vqaf_select_desc* descs_host, int n, int B, int H, const uint64_t* rng_state,
+                      vqaf_stream_t stream);
 
 /* counter += delta on the device (stream-ordered; graph-capturable). */
 int vqaf_rng_advance(uint64_t* rng_state, uint64_t delta, vqaf_stream_t stream);

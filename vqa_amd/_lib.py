@@ -29,6 +29,24 @@ class PoolMod(ctypes.Structure):
                 ("K", c_int), ("col0", c_int)]
 
 
+class FoldDesc(ctypes.Structure):
+    """vqaf_fold_desc of include/vqaf.h."""
+    _fields_ = [("q", c_void_p), ("in_proj_weight", c_void_p), ("in_proj_bias", c_void_p),
+                ("qproj_ws", c_void_p), ("u", c_void_p)]
+
+
+class ScoresDesc(ctypes.Structure):
+    """vqaf_scores_desc of include/vqaf.h."""
+    _fields_ = [("seq", c_void_p), ("u", c_void_p), ("s", c_void_p), ("N", c_int)]
+
+
+class SelectDesc(ctypes.Structure):
+    """vqaf_select_desc of include/vqaf.h."""
+    _fields_ = [("s", c_void_p), ("w_in", c_void_p), ("pos", c_void_p), ("src", c_void_p), ("w_out", c_void_p),
+                ("top", c_void_p), ("bottom", c_void_p), ("pos_out", c_void_p), ("src_out", c_void_p),
+                ("salt", c_uint64), ("N", c_int), ("K", c_int), ("adv_mode", c_int), ("k_adv", c_int)]
+
+
 class PoolBwdMod(ctypes.Structure):
     """vqaf_pool_bwd_mod of include/vqaf.h."""
     _fields_ = [("idx", c_void_p), ("grad_seq", c_void_p), ("alpha", c_float), ("N", c_int), ("K", c_int),
@@ -40,7 +58,9 @@ SIGNATURES = {
     "vqaf_version": (c_int, []),
     "vqaf_status_string": (c_char_p, [c_int]),
     "vqaf_fold_query": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "vqaf_fold_query_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "vqaf_head_scores": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "vqaf_head_scores_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vqaf_attn_weights": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "vqaf_score_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vqaf_score": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t,
@@ -50,6 +70,7 @@ SIGNATURES = {
     "vqaf_adv_swap_random": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "vqaf_select": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_uint64, _P, _P, _P,
                             _P, _P, _P]),
+    "vqaf_select_multi": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "vqaf_rng_advance": (c_int, [_P, c_uint64, _P]),
     "vqaf_gather_mix": (c_int, [_P, _P, _P, c_int, c_float, _P, c_float, c_int, c_int, c_int,
                                 c_int, c_int, c_int, _P, _P]),

@@ -101,15 +101,30 @@ __device__ __forceinline__ void store_tile(float (*T)[GP], int tid, const u32x4 
 // through registers, then each wave feeds v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fmaf
 // chain) one k pair at a time: lane l supplies A[m = l & 31][k = l >> 5] and
 // B[k = l >> 5][n = l & 31].
+// Up to four independent problems of the same shape (different operand pointers) share one launch:
+// blockIdx.z = set * gper + g.  Small GEMMs that would each fill half the chip then fill it together.
+constexpr int GEMM_MAX_SETS = 4;
+struct GemmSets {
+  const void* A[GEMM_MAX_SETS];
+  const void* Bm[GEMM_MAX_SETS];
+  const void* bias[GEMM_MAX_SETS];
+  float* C[GEMM_MAX_SETS];
+  int gper;  // batches per set
+};
+
 template <int AMODE, int BMODE, bool A_BF16, bool B_BF16>
 __global__ void __launch_bounds__(GTHREADS)
-gemm_f32_kernel(const void* __restrict__ A, long a_sg, long a_sm, long a_sk,
-                const void* __restrict__ Bm, long b_sg, long b_sk, long b_sn,
-                const void* __restrict__ bias, int bias_bf16, long bias_sg, float* __restrict__ C,
-                long c_sg, long c_sm, int M, int N, int K, float alpha, int beta_one) {
+gemm_f32_kernel(GemmSets sets, long a_sg, long a_sm, long a_sk, long b_sg, long b_sk, long b_sn,
+                int bias_bf16, long bias_sg, long c_sg, long c_sm, int M, int N, int K, float alpha,
+                int beta_one) {
   __shared__ float As[2][GK][GP];
   __shared__ float Bs[2][GK][GP];
-  const int g = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int set = blockIdx.z / sets.gper;
+  const void* __restrict__ A = sets.A[set];
+  const void* __restrict__ Bm = sets.Bm[set];
+  const void* __restrict__ bias = sets.bias[set];
+  float* __restrict__ C = sets.C[set];
+  const int g = blockIdx.z % sets.gper, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
   f32x16 acc;
@@ -174,27 +189,31 @@ int pick_mode(const void* p, int dtype, long sg, long sx, long sk, int X, int K)
   return G_SCALAR;
 }
 
-}  // namespace
-
-extern "C" int vqaf_gemm_f32(const void* A, int a_dtype, long a_sg, long a_sm, long a_sk,
-                             const void* Bm, int b_dtype, long b_sg, long b_sk, long b_sn,
-                             const void* bias, int bias_dtype, long bias_sg, float* C, long c_sg,
-                             long c_sm, int G, int M, int N, int K, float alpha, int beta_one,
-                             vqaf_stream_t stream) {
-  VQAF_ENTRY();
-  VQAF_REQUIRE(A != nullptr && Bm != nullptr && C != nullptr, VQAF_E_NULL);
+// Launches `nsets` problems of identical shape / strides / dtypes in one grid.
+int gemm_launch(const GemmSets& sets, int nsets, int a_dtype, long a_sg, long a_sm, long a_sk, int b_dtype,
+                long b_sg, long b_sk, long b_sn, int bias_dtype, long bias_sg, long c_sg, long c_sm, int G,
+                int M, int N, int K, float alpha, int beta_one, hipStream_t st) {
+  VQAF_REQUIRE(nsets > 0 && nsets <= GEMM_MAX_SETS, VQAF_E_SHAPE);
   VQAF_REQUIRE(vqaf_dtype_ok(a_dtype) && vqaf_dtype_ok(b_dtype), VQAF_E_DTYPE);
-  VQAF_REQUIRE(bias == nullptr || vqaf_dtype_ok(bias_dtype), VQAF_E_DTYPE);
-  VQAF_REQUIRE(G > 0 && M > 0 && N > 0 && K > 0 && G <= 65535, VQAF_E_SHAPE);
-  const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, G), block(GTHREADS);
+  VQAF_REQUIRE(G > 0 && M > 0 && N > 0 && K > 0 && (long)G * nsets <= 65535, VQAF_E_SHAPE);
+  int am = G_KVEC, bm = G_KVEC;
+  bool first = true;
+  for (int i = 0; i < nsets; ++i) {
+    VQAF_REQUIRE(sets.A[i] != nullptr && sets.Bm[i] != nullptr && sets.C[i] != nullptr, VQAF_E_NULL);
+    VQAF_REQUIRE(sets.bias[i] == nullptr || vqaf_dtype_ok(bias_dtype), VQAF_E_DTYPE);
+    const int ai = pick_mode(sets.A[i], a_dtype, a_sg, a_sm, a_sk, M, K);
+    const int bi = pick_mode(sets.Bm[i], b_dtype, b_sg, b_sn, b_sk, N, K);
+    if (first) { am = ai; bm = bi; first = false; }
+    if (ai != am) am = G_SCALAR;  // the sets must share one staging mode
+    if (bi != bm) bm = G_SCALAR;
+  }
+  const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, G * nsets), block(GTHREADS);
   VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);
-  hipStream_t st = (hipStream_t)stream;
   const int bias_bf16 = bias_dtype == VQAF_BF16;
   const bool ab = a_dtype == VQAF_BF16, bb = b_dtype == VQAF_BF16;
-  const int am = pick_mode(A, a_dtype, a_sg, a_sm, a_sk, M, K), bm = pick_mode(Bm, b_dtype, b_sg, b_sn, b_sk, N, K);
-#define VQAF_GEMM_LAUNCH(AM, BM_, AB, BB)                                                              \
-  hipLaunchKernelGGL((gemm_f32_kernel<AM, BM_, AB, BB>), grid, block, 0, st, A, a_sg, a_sm, a_sk, Bm,   \
-                     b_sg, b_sk, b_sn, bias, bias_bf16, bias_sg, C, c_sg, c_sm, M, N, K, alpha, beta_one)
+#define VQAF_GEMM_LAUNCH(AM, BM_, AB, BB)                                                             \
+  hipLaunchKernelGGL((gemm_f32_kernel<AM, BM_, AB, BB>), grid, block, 0, st, sets, a_sg, a_sm, a_sk,   \
+                     b_sg, b_sk, b_sn, bias_bf16, bias_sg, c_sg, c_sm, M, N, K, alpha, beta_one)
 #define VQAF_GEMM_BY_DT(AM, BM_)                            \
   do {                                                      \
     if (ab && bb) VQAF_GEMM_LAUNCH(AM, BM_, true, true);    \
@@ -216,4 +235,55 @@ extern "C" int vqaf_gemm_f32(const void* A, int a_dtype, long a_sg, long a_sm, l
 #undef VQAF_GEMM_BY_DT
 #undef VQAF_GEMM_LAUNCH
   VQAF_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" int vqaf_gemm_f32(const void* A, int a_dtype, long a_sg, long a_sm, long a_sk,
+                             const void* Bm, int b_dtype, long b_sg, long b_sk, long b_sn,
+                             const void* bias, int bias_dtype, long bias_sg, float* C, long c_sg,
+                             long c_sm, int G, int M, int N, int K, float alpha, int beta_one,
+                             vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(A != nullptr && Bm != nullptr && C != nullptr, VQAF_E_NULL);
+  GemmSets sets = {};
+  sets.A[0] = A;
+  sets.Bm[0] = Bm;
+  sets.bias[0] = bias;
+  sets.C[0] = C;
+  sets.gper = G;
+  return gemm_launch(sets, 1, a_dtype, a_sg, a_sm, a_sk, b_dtype, b_sg, b_sk, b_sn, bias_dtype, bias_sg, c_sg,
+                     c_sm, G, M, N, K, alpha, beta_one, (hipStream_t)stream);
+}
+
+// u_i (B,H,D) for several (query, in_proj) pairs of one shape: two launches in total (see
+// vqaf_fold_query for the arithmetic).
+extern "C" int vqaf_fold_query_multi(const vqaf_fold_desc* descs_host, int n, int B, int D, int H, int dtype,
+                                     int w_dtype, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(descs_host != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(n > 0 && n <= GEMM_MAX_SETS && B > 0 && D > 0 && H > 0 && D % H == 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(w_dtype), VQAF_E_DTYPE);
+  const int dh = D / H;
+  const size_t esz = vqaf_esize(w_dtype);
+  GemmSets s1 = {}, s2 = {};
+  for (int i = 0; i < n; ++i) {
+    const vqaf_fold_desc& d = descs_host[i];
+    VQAF_REQUIRE(d.q && d.in_proj_weight && d.in_proj_bias && d.qproj_ws && d.u, VQAF_E_NULL);
+    s1.A[i] = d.q;
+    s1.Bm[i] = d.in_proj_weight;
+    s1.bias[i] = d.in_proj_bias;
+    s1.C[i] = d.qproj_ws;
+    s2.A[i] = d.qproj_ws;
+    s2.Bm[i] = reinterpret_cast<const unsigned char*>(d.in_proj_weight) + (size_t)D * D * esz;
+    s2.bias[i] = nullptr;
+    s2.C[i] = d.u;
+  }
+  s1.gper = 1;
+  s2.gper = H;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = gemm_launch(s1, n, dtype, 0, D, 1, w_dtype, 0, 1, D, w_dtype, 0, 0, D, 1, B, D, D, 1.0f, 0, st);
+  if (rc != VQAF_OK) return rc;
+  return gemm_launch(s2, n, VQAF_F32, dh, D, 1, w_dtype, (long)dh * D, D, 1, 0, 0, D, (long)H * D, H, B, D, dh,
+                     1.0f / sqrtf((float)dh), 0, st);
 }

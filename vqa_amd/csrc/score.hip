@@ -123,15 +123,27 @@ head_scores_kernel(const void* __restrict__ seq, const float* __restrict__ u, in
 // h + 8 = bf16(u_h - bf16(u_h)) (rows padded by 16 B: conflict-free ds_read_b128), shared by the
 // four waves; token tiles are prefetched one tile ahead, the first one before the LDS staging.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// Up to four token sets of different length scored by one launch (blockIdx.z picks the set).
+constexpr int SC_MAX_MODS = 4;
+struct ScoreMods {
+  const bf16_t* seq[SC_MAX_MODS];
+  const float* u[SC_MAX_MODS];
+  float* s[SC_MAX_MODS];
+  int N[SC_MAX_MODS];
+};
 template <int STEPS>
 __global__ void __launch_bounds__(SC_THREADS)
-head_scores_mfma_kernel(const bf16_t* __restrict__ seq, const float* __restrict__ u, int N, int H,
-                        int tokb, float* __restrict__ s) {
+head_scores_mfma_kernel(ScoreMods mods, int H, int tokb) {
   constexpr int D = 32 * STEPS;
   constexpr int PITCH = D + 8;
   __shared__ __attribute__((aligned(16))) bf16_t ub[16 * PITCH];
+  const bf16_t* __restrict__ seq = mods.seq[blockIdx.z];
+  const float* __restrict__ u = mods.u[blockIdx.z];
+  float* __restrict__ s = mods.s[blockIdx.z];
+  const int N = mods.N[blockIdx.z];
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * tokb;
+  if (t0 >= N) return;  // a shorter set needs fewer token blocks
   const int t1 = min(N, t0 + tokb);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int col = lane & 15, kg = lane >> 4;
@@ -274,6 +286,8 @@ extern "C" int vqaf_fold_query(const void* q, const void* in_proj_weight, const 
                        u, D, (long)H * D, H, B, D, dh, 1.0f / sqrtf((float)dh), 0, stream);
 }
 
+static int launch_scores_mfma(const ScoreMods& mods, int n, int B, int Nmax, int D, int H, hipStream_t st);
+
 static bool mfma_steps_ok(int D) {
   return D == 64 || D == 128 || D == 256 || D == 512 || D == 768 || D == 1024;
 }
@@ -286,28 +300,12 @@ extern "C" int vqaf_head_scores(const void* seq, const float* u, int B, int N, i
   VQAF_REQUIRE(B > 0 && N > 0 && D > 0 && H > 0 && B <= 65535, VQAF_E_SHAPE);
   VQAF_REQUIRE(D % 8 == 0 && vqaf_aligned16(seq) && vqaf_aligned16(u), VQAF_E_ALIGN);
   if (dtype == VQAF_BF16 && H <= 8 && mfma_steps_ok(D)) {
-    static const int forced_tokb = [] {
-      const char* e = getenv("VQAF_HS_TOKB");  // tuning knob: tokens per workgroup (multiple of 64)
-      return e ? atoi(e) : 0;
-    }();
-    int tokb = 64;
-    if ((long)B * ((N + 127) / 128) >= 512) tokb = 128;
-    if ((long)B * ((N + 255) / 256) >= 1024) tokb = 256;
-    if (forced_tokb >= 64 && forced_tokb % 64 == 0) tokb = forced_tokb;
-    const dim3 grid((N + tokb - 1) / tokb, B), block(SC_THREADS);
-    hipStream_t st = (hipStream_t)stream;
-    const bf16_t* x = reinterpret_cast<const bf16_t*>(seq);
-#define VQAF_HSM(S) hipLaunchKernelGGL(head_scores_mfma_kernel<S>, grid, block, 0, st, x, u, N, H, tokb, s)
-    switch (D / 32) {
-      case 2: VQAF_HSM(2); break;
-      case 4: VQAF_HSM(4); break;
-      case 8: VQAF_HSM(8); break;
-      case 16: VQAF_HSM(16); break;
-      case 24: VQAF_HSM(24); break;
-      default: VQAF_HSM(32); break;
-    }
-#undef VQAF_HSM
-    VQAF_LAUNCH_CHECK();
+    ScoreMods mods = {};
+    mods.seq[0] = reinterpret_cast<const bf16_t*>(seq);
+    mods.u[0] = u;
+    mods.s[0] = s;
+    mods.N[0] = N;
+    return launch_scores_mfma(mods, 1, B, N, D, H, (hipStream_t)stream);
   }
   const int HP = pad_heads(H);
   const int CH = (D + 511) / 512;
@@ -343,6 +341,59 @@ extern "C" int vqaf_head_scores(const void* seq, const float* u, int B, int N, i
   }
 #undef VQAF_HS
   VQAF_LAUNCH_CHECK();
+}
+
+static int launch_scores_mfma(const ScoreMods& mods, int n, int B, int Nmax, int D, int H, hipStream_t st) {
+  static const int forced_tokb = [] {
+    const char* e = getenv("VQAF_HS_TOKB");  // tuning knob: tokens per workgroup (multiple of 64)
+    return e ? atoi(e) : 0;
+  }();
+  int tokb = 64;
+  if ((long)B * ((Nmax + 127) / 128) >= 512) tokb = 128;
+  if ((long)B * ((Nmax + 255) / 256) >= 1024) tokb = 256;
+  if (forced_tokb >= 64 && forced_tokb % 64 == 0) tokb = forced_tokb;
+  const dim3 grid((Nmax + tokb - 1) / tokb, B, n), block(SC_THREADS);
+#define VQAF_HSM(S) hipLaunchKernelGGL(head_scores_mfma_kernel<S>, grid, block, 0, st, mods, H, tokb)
+  switch (D / 32) {
+    case 2: VQAF_HSM(2); break;
+    case 4: VQAF_HSM(4); break;
+    case 8: VQAF_HSM(8); break;
+    case 16: VQAF_HSM(16); break;
+    case 24: VQAF_HSM(24); break;
+    default: VQAF_HSM(32); break;
+  }
+#undef VQAF_HSM
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_head_scores_multi(const vqaf_scores_desc* descs_host, int n, int B, int D, int H,
+                                      int dtype, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(descs_host != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(n > 0 && n <= SC_MAX_MODS && B > 0 && B <= 65535 && D > 0 && H > 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  if (!(dtype == VQAF_BF16 && H <= 8 && mfma_steps_ok(D))) {
+    for (int i = 0; i < n; ++i) {  // other shapes: one launch per set
+      const int rc = vqaf_head_scores(descs_host[i].seq, descs_host[i].u, B, descs_host[i].N, D, H, dtype,
+                                      descs_host[i].s, stream);
+      if (rc != VQAF_OK) return rc;
+    }
+    return VQAF_OK;
+  }
+  ScoreMods mods = {};
+  int nmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const vqaf_scores_desc& d = descs_host[i];
+    VQAF_REQUIRE(d.seq && d.u && d.s, VQAF_E_NULL);
+    VQAF_REQUIRE(d.N > 0, VQAF_E_SHAPE);
+    VQAF_REQUIRE(vqaf_aligned16(d.seq) && vqaf_aligned16(d.u), VQAF_E_ALIGN);
+    mods.seq[i] = reinterpret_cast<const bf16_t*>(d.seq);
+    mods.u[i] = d.u;
+    mods.s[i] = d.s;
+    mods.N[i] = d.N;
+    nmax = d.N > nmax ? d.N : nmax;
+  }
+  return launch_scores_mfma(mods, n, B, nmax, D, H, (hipStream_t)stream);
 }
 
 extern "C" int vqaf_attn_weights(const float* s, int B, int N, int H, float* w,

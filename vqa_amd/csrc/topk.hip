@@ -168,13 +168,37 @@ __global__ void adv_swap_random_kernel(int64_t* __restrict__ top, const int64_t*
 // draws.  Replaces four launches (weights, top-k, swap, counter bump is still separate) and keeps
 // the weights and both index lists in LDS in between.
 constexpr int SEL_MAX_H = 16;
-__global__ void select_kernel(const float* __restrict__ s, const float* __restrict__ w_in, int N, int H,
-                              int K, int NP, int adv_mode, int k_adv, int NPK, int NPR,
-                              const int64_t* __restrict__ pos, const int64_t* __restrict__ src,
-                              const uint64_t* __restrict__ rng_state, unsigned long long salt,
-                              float* __restrict__ w_out, int64_t* __restrict__ top,
-                              int64_t* __restrict__ bottom, int64_t* __restrict__ pos_out,
-                              int64_t* __restrict__ src_out) {
+constexpr int SEL_MAX_MODS = 4;
+struct SelectMod {
+  const float* s;
+  const float* w_in;
+  const int64_t* pos;
+  const int64_t* src;
+  float* w_out;
+  int64_t* top;
+  int64_t* bottom;
+  int64_t* pos_out;
+  int64_t* src_out;
+  unsigned long long salt;
+  int N, K, NP, adv_mode, k_adv, NPK, NPR;
+};
+struct SelectMods {
+  SelectMod m[SEL_MAX_MODS];
+};
+__global__ void select_kernel(SelectMods mods, int H, const uint64_t* __restrict__ rng_state) {
+  const SelectMod& M_ = mods.m[blockIdx.y];
+  const float* __restrict__ s = M_.s;
+  const float* __restrict__ w_in = M_.w_in;
+  const int64_t* __restrict__ pos = M_.pos;
+  const int64_t* __restrict__ src = M_.src;
+  float* __restrict__ w_out = M_.w_out;
+  int64_t* __restrict__ top = M_.top;
+  int64_t* __restrict__ bottom = M_.bottom;
+  int64_t* __restrict__ pos_out = M_.pos_out;
+  int64_t* __restrict__ src_out = M_.src_out;
+  const unsigned long long salt = M_.salt;
+  const int N = M_.N, K = M_.K, NP = M_.NP, adv_mode = M_.adv_mode, k_adv = M_.k_adv, NPK = M_.NPK,
+            NPR = M_.NPR;
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [NP]
   float* sl = reinterpret_cast<float*>(keys + NP);                           // [N*H] head scores (16-B aligned)
   const int slots = (s != nullptr) ? ((N * H + 3) & ~3) : 0;
@@ -311,14 +335,13 @@ extern "C" int vqaf_adv_swap_random(int64_t* top, const int64_t* bottom, int B, 
   VQAF_LAUNCH_CHECK();
 }
 
-extern "C" int vqaf_select(const float* s, const float* w_in, int B, int N, int H, int K, int adv_mode,
-                           int k_adv, const int64_t* pos, const int64_t* src,
-                           const uint64_t* rng_state, uint64_t salt, float* w_out, int64_t* top,
-                           int64_t* bottom, int64_t* pos_out, int64_t* src_out, vqaf_stream_t stream) {
-  VQAF_ENTRY();
+static int select_fill(SelectMod& m, const float* s, const float* w_in, int N, int H, int K, int adv_mode,
+                       int k_adv, const int64_t* pos, const int64_t* src, const uint64_t* rng_state,
+                       uint64_t salt, float* w_out, int64_t* top, int64_t* bottom, int64_t* pos_out,
+                       int64_t* src_out, size_t* smem, int* threads) {
   VQAF_REQUIRE((s != nullptr) != (w_in != nullptr), VQAF_E_NULL);  // exactly one source of weights
   VQAF_REQUIRE(top != nullptr, VQAF_E_NULL);
-  VQAF_REQUIRE(B > 0 && N > 0 && K > 0 && K <= N && N <= TK_MAX_N, VQAF_E_SHAPE);
+  VQAF_REQUIRE(N > 0 && K > 0 && K <= N && N <= TK_MAX_N, VQAF_E_SHAPE);
   VQAF_REQUIRE(s == nullptr || (H > 0 && H <= SEL_MAX_H), VQAF_E_SHAPE);
   VQAF_REQUIRE(adv_mode >= 0 && adv_mode <= 2, VQAF_E_SHAPE);
   const int R = N - K;
@@ -329,15 +352,50 @@ extern "C" int vqaf_select(const float* s, const float* w_in, int B, int N, int 
   } else {
     k_adv = 0;
   }
-  const int NP = next_pow2(N), NPK = next_pow2(K), NPR = next_pow2(R > 0 ? R : 1);
-  const size_t smem = (size_t)NP * 8 + (size_t)N * 4 + (size_t)(k_adv > 0 ? 2 * k_adv : 1) * 4 + (size_t)N * 4 +
+  const int NP = next_pow2(N);
+  m = SelectMod{s, w_in, pos, src, w_out, top, bottom, pos_out, src_out, (unsigned long long)salt,
+                N, K, NP, adv_mode, k_adv, next_pow2(K), next_pow2(R > 0 ? R : 1)};
+  const size_t need = (size_t)NP * 8 + (size_t)N * 4 + (size_t)(k_adv > 0 ? 2 * k_adv : 1) * 4 + (size_t)N * 4 +
                       (s != nullptr ? (size_t)((N * H + 3) & ~3) * 4 : 0);
-  VQAF_REQUIRE(smem <= 64 * 1024, VQAF_E_SHAPE);
-  int threads = sort_threads(NP);
-  if (threads < 256) threads = 256;  // the score / weight passes want more lanes than the sort
-  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(threads), smem, (hipStream_t)stream, s, w_in, N, H, K,
-                     NP, adv_mode, k_adv, NPK, NPR, pos, src, rng_state, (unsigned long long)salt, w_out,
-                     top, bottom, pos_out, src_out);
+  VQAF_REQUIRE(need <= 64 * 1024, VQAF_E_SHAPE);
+  *smem = need > *smem ? need : *smem;
+  int t = sort_threads(NP);
+  if (t < 256) t = 256;  // the score / weight passes want more lanes than the sort
+  *threads = t > *threads ? t : *threads;
+  return VQAF_OK;
+}
+
+extern "C" int vqaf_select(const float* s, const float* w_in, int B, int N, int H, int K, int adv_mode,
+                           int k_adv, const int64_t* pos, const int64_t* src,
+                           const uint64_t* rng_state, uint64_t salt, float* w_out, int64_t* top,
+                           int64_t* bottom, int64_t* pos_out, int64_t* src_out, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(B > 0, VQAF_E_SHAPE);
+  SelectMods mods = {};
+  size_t smem = 0;
+  int threads = 0;
+  const int rc = select_fill(mods.m[0], s, w_in, N, H, K, adv_mode, k_adv, pos, src, rng_state, salt, w_out, top,
+                             bottom, pos_out, src_out, &smem, &threads);
+  if (rc != VQAF_OK) return rc;
+  hipLaunchKernelGGL(select_kernel, dim3(B, 1), dim3(threads), smem, (hipStream_t)stream, mods, H, rng_state);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_select_multi(const vqaf_select_desc* descs_host, int n, int B, int H,
+                                 const uint64_t* rng_state, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(descs_host != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(n > 0 && n <= SEL_MAX_MODS && B > 0, VQAF_E_SHAPE);
+  SelectMods mods = {};
+  size_t smem = 0;
+  int threads = 0;
+  for (int i = 0; i < n; ++i) {
+    const vqaf_select_desc& d = descs_host[i];
+    const int rc = select_fill(mods.m[i], d.s, d.w_in, d.N, H, d.K, d.adv_mode, d.k_adv, d.pos, d.src, rng_state,
+                               d.salt, d.w_out, d.top, d.bottom, d.pos_out, d.src_out, &smem, &threads);
+    if (rc != VQAF_OK) return rc;
+  }
+  hipLaunchKernelGGL(select_kernel, dim3(B, n), dim3(threads), smem, (hipStream_t)stream, mods, H, rng_state);
   VQAF_LAUNCH_CHECK();
 }
 

@@ -73,6 +73,17 @@ class PrivacyAwareTokenPruning(nn.Module):
         self._drew = res["drew"]  # True if the kernel consumed random numbers (caller may batch the advance)
         return res["top"]
 
+    def plan(self, n_tokens: int):
+        """(k, k_adv) for a sequence of n_tokens: tokens kept (utils/fusion.py:41) and keep slots
+        swapped adversarially (:54; 0 when mixing is off or skipped by the guard at :57)."""
+        k = ops.keep_count(n_tokens, self.prune_ratio)
+        k_adv = 0
+        if self.adversarial_mix:
+            k_adv = ops.adv_count(k, self.adv_ratio)
+            if n_tokens - k < k_adv:
+                k_adv = 0
+        return k, k_adv
+
     def _noise_args(self, noise: Optional[torch.Tensor]):
         if not self.noise_injection:
             return None, None
@@ -141,6 +152,7 @@ class Attention(nn.Module):
                                                     adversarial_mix=adversarial_mix, adv_ratio=adv_ratio)
 
     def forward(self, v_seq, v_global, q_seq, q_global, **inject):
+        ops.require_gpu(v_seq)  # no CPU fallback: fail before anything else is touched
         if self.use_pruning:
             if self.fuse_pool:
                 hs = _head_scores(self.attention, q_global, v_seq)
@@ -182,9 +194,38 @@ class CoAttention(nn.Module):
         replay pre-drawn randomness in the vision / text pruning (parity tests)."""
         v_inject = v_inject or {}
         q_inject = q_inject or {}
+        ops.require_gpu(v_seq, q_seq)  # no CPU fallback: fail before anything else is touched
         if self.use_pruning:
             if self.fuse_pool:
-                # both selections draw from the same counter with different salts; one advance after
+                # Both branches go through the same four launches (query folds x2, token scoring,
+                # selection); they draw from one counter with different salts, advanced once.
+                a_v, a_q = self.txt_to_vis_attn, self.vis_to_txt_attn
+                uniform = (v_seq.shape[0] == q_seq.shape[0] and v_seq.shape[2] == q_seq.shape[2]
+                           and v_seq.dtype == q_seq.dtype and a_v.num_heads == a_q.num_heads
+                           and a_v.in_proj_weight.dtype == a_q.in_proj_weight.dtype
+                           and (self.v_pruning.rng is self.q_pruning.rng))
+                if uniform:
+                    specs = []
+                    for salt, (mha, query, seq, prune, inj) in enumerate((
+                            (a_v, q_global, v_seq, self.v_pruning, v_inject),      # utils/fusion.py:234-240
+                            (a_q, v_global, q_seq, self.q_pruning, q_inject))):    # utils/fusion.py:243-249
+                        k, k_adv = prune.plan(seq.shape[1])
+                        specs.append(dict(q=query, seq=seq, in_proj_weight=mha.in_proj_weight,
+                                          in_proj_bias=mha.in_proj_bias, num_heads=mha.num_heads, k=k,
+                                          k_adv=k_adv, pos=inj.get("replace_positions"),
+                                          src=inj.get("random_bottom"), salt=salt))
+                    rng = self.v_pruning.rng or ops.default_rng(v_seq.device)
+                    (v_idx, q_idx), drew = ops.score_select_multi(specs, rng)
+                    if drew:
+                        rng.advance()
+                    self.v_pruning.last_indices, self.q_pruning.last_indices = v_idx, q_idx
+                    v_noise, v_ntype = self.v_pruning._noise_args(v_inject.get("noise"))
+                    v_spec = dict(seq=v_seq, idx=v_idx, alpha=float(self.v_pruning.mixup_alpha), noise=v_noise,
+                                  noise_type=v_ntype, noise_scale=float(self.v_pruning.noise_scale),
+                                  rng=self.v_pruning.rng)
+                    q_spec = dict(seq=q_seq, idx=q_idx, alpha=float(self.q_pruning.mixup_alpha), noise=None,
+                                  noise_type=None, noise_scale=0.0, rng=self.q_pruning.rng)
+                    return ops.pruned_pool([v_spec, q_spec], v_seq.dtype)          # :253-254, :274
                 v_hs = _head_scores(self.txt_to_vis_attn, q_global, v_seq)   # utils/fusion.py:234-238
                 v_spec = self.v_pruning.pool_spec(v_seq, None, head_scores=v_hs, salt=0, advance=False,
                                                   **v_inject)

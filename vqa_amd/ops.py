@@ -61,6 +61,13 @@ def _probe(name: str, phase: str) -> None:
         PROBE(name, phase)
 
 
+def require_gpu(*tensors: torch.Tensor) -> None:
+    """Raises the library's "GPU only" error for CPU tensors (there is no CPU fallback)."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            ptr(t)
+
+
 def _noise_kind(noise_type: Optional[str]) -> int:
     if noise_type is None:
         return _lib.NOISE_NONE
@@ -162,6 +169,65 @@ def select_indices(k: int, *, scores: Optional[torch.Tensor] = None, weights: Op
     if mode == 2 and advance:
         rng.advance()
     return out
+
+
+@torch.no_grad()
+def score_select_multi(specs, rng: Optional["PhiloxState"] = None):
+    """Scoring + keep-index selection for several modalities that share batch, width, head count
+    and dtypes (CoAttention's two branches) in FOUR launches in total: two for all query folds, one
+    for all token scoring passes, one for all selections.
+
+    specs: list of dicts(q, seq, in_proj_weight, in_proj_bias, num_heads, k, k_adv, pos, src, salt).
+    Returns (list of keep-index tensors (B,k_i) int64, drew) where `drew` tells whether random
+    numbers were consumed (the caller advances `rng` once)."""
+    import ctypes
+    n = len(specs)
+    seq0 = specs[0]["seq"]
+    B, _, D = seq0.shape
+    H = specs[0]["num_heads"]
+    dev = seq0.device
+    ptr(seq0.contiguous())  # fails loudly on CPU tensors before any device call
+    lib, st = load(), stream_ptr(dev)
+    w_dt = specs[0]["in_proj_weight"].dtype
+    keep = []  # keeps every temporary alive until the launches are enqueued
+    folds = (_lib.FoldDesc * n)()
+    scores = (_lib.ScoresDesc * n)()
+    sels = (_lib.SelectDesc * n)()
+    tops, drew = [], False
+    for i, sp in enumerate(specs):
+        seq = sp["seq"].contiguous()
+        N = seq.shape[1]
+        q = sp["q"].reshape(B, D).to(seq.dtype).contiguous()
+        w_ = sp["in_proj_weight"].detach().contiguous()
+        b_ = sp["in_proj_bias"].detach().to(w_.dtype).contiguous()
+        qp = torch.empty(B, D, dtype=torch.float32, device=dev)
+        u = torch.empty(B, H, D, dtype=torch.float32, device=dev)
+        sc = torch.empty(B, N, H, dtype=torch.float32, device=dev)
+        top = torch.empty(B, sp["k"], dtype=torch.int64, device=dev)
+        k_adv = int(sp.get("k_adv", 0))
+        pos, src = sp.get("pos"), sp.get("src")
+        mode = 0
+        if k_adv > 0:
+            mode = 1 if pos is not None else 2
+            if mode == 1:
+                pos, src = pos.to(torch.int64).contiguous(), src.to(torch.int64).contiguous()
+            else:
+                drew = True
+        keep.append((seq, q, w_, b_, qp, u, sc, pos, src))
+        folds[i] = _lib.FoldDesc(ptr(q), ptr(w_), ptr(b_), ptr(qp), ptr(u))
+        scores[i] = _lib.ScoresDesc(ptr(seq), ptr(u), ptr(sc), N)
+        sels[i] = _lib.SelectDesc(ptr(sc), None, ptr(pos) if mode == 1 else None, ptr(src) if mode == 1 else None,
+                                  None, ptr(top), None, None, None, int(sp.get("salt", i)), N, sp["k"], mode, k_adv)
+        tops.append(top)
+    if drew and rng is None:
+        rng = default_rng(dev)
+    check(lib.vqaf_fold_query_multi(ctypes.cast(folds, ctypes.c_void_p), n, B, D, H, dtype_code(seq0),
+                                    _lib.BF16 if w_dt == torch.bfloat16 else _lib.F32, st), "vqaf_fold_query_multi")
+    check(lib.vqaf_head_scores_multi(ctypes.cast(scores, ctypes.c_void_p), n, B, D, H, dtype_code(seq0), st),
+          "vqaf_head_scores_multi")
+    check(lib.vqaf_select_multi(ctypes.cast(sels, ctypes.c_void_p), n, B, H, ptr(rng.state) if drew else None, st),
+          "vqaf_select_multi")
+    return tops, drew
 
 
 @torch.no_grad()
