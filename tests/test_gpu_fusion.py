@@ -479,3 +479,38 @@ def test_fused_select_equals_separate_kernels(dev):
         top_b = top_sep.clone()
         ops.adv_swap_(top_b, bot_sep, pos.to(dev), src.to(dev))
         assert torch.equal(r4["top"], top_b)
+
+
+def test_multi_branch_launches_equal_single_branch_calls(dev):
+    """ops.score_select_multi (folds, scoring and selection of both CoAttention branches in four
+    launches) against the per-branch entry points: same head scores, same keep lists, same draws."""
+    from vqa_amd import ops
+    B, Nv, Nq, D, H = 6, 197, 30, 512, 8
+    for dt in (torch.float32, torch.bfloat16):
+        v_seq, v_global = gi.tokens(1, B, Nv)
+        q_seq, q_global = gi.tokens(2, B, Nq)
+        pv, pq = gi.mha_params(3), gi.mha_params(7)
+        to = lambda t: t.to(dev).to(dt)  # noqa: E731
+        specs, want = [], []
+        for salt, (query, seq, p, N) in enumerate(((q_global, v_seq, pv, Nv), (v_global, q_seq, pq, Nq))):
+            k = fo.keep_count(N, 0.5)
+            k_adv = fo.adv_count(k, 0.2)
+            specs.append(dict(q=to(query), seq=to(seq), in_proj_weight=to(p["in_proj_weight"]),
+                              in_proj_bias=to(p["in_proj_bias"]), num_heads=H, k=k, k_adv=k_adv, salt=salt))
+            hs = ops.head_score_matrix(to(query), to(seq), to(p["in_proj_weight"]), to(p["in_proj_bias"]), H)
+            r = ops.select_indices(k, scores=hs, k_adv=k_adv, rng=ops.PhiloxState(dev, seed=11), salt=salt)
+            want.append(r["top"])
+        tops, drew = ops.score_select_multi(specs, ops.PhiloxState(dev, seed=11))
+        assert drew
+        for got, w in zip(tops, want):
+            assert torch.equal(got, w)
+        # injected draws and no swap at all
+        for sp, N in zip(specs, (Nv, Nq)):
+            pos, src = gi.adversarial_draws(5, B, sp["k"], N - sp["k"], sp["k_adv"])
+            sp["pos"], sp["src"] = pos.to(dev), src.to(dev)
+        tops2, drew2 = ops.score_select_multi(specs, None)
+        assert not drew2
+        for sp, got in zip(specs, tops2):
+            hs = ops.head_score_matrix(sp["q"], sp["seq"], sp["in_proj_weight"], sp["in_proj_bias"], H)
+            r = ops.select_indices(sp["k"], scores=hs, k_adv=sp["k_adv"], pos=sp["pos"], src=sp["src"])
+            assert torch.equal(got, r["top"])
