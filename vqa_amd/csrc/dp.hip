@@ -311,8 +311,19 @@ __device__ __forceinline__ unsigned int scale_pack2(unsigned int w, float c, flo
 template <int VEC_G, int VEC_A>
 __global__ void __launch_bounds__(DP_THREADS)
 clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ g,
-                               const float* __restrict__ coef, int B, int In, int Out,
-                               int accumulate, float* __restrict__ SW, float* __restrict__ Sb) {
+                               const float* __restrict__ coef, int Btot, int In, int Out,
+                               int accumulate, float* __restrict__ SW, float* __restrict__ Sb,
+                               int rows_per_split) {
+  // blockIdx.z owns the batch rows [b_lo, b_hi): with more than one split the partial tiles are
+  // added to the (pre-zeroed) output with f32 atomics -- used only when the output has too few
+  // tiles to occupy the chip (the 430 x 1024 head).
+  const int b_lo = blockIdx.z * rows_per_split;
+  const int B = min(Btot, b_lo + rows_per_split) - b_lo;
+  const bool split = gridDim.z > 1;
+  if (B <= 0) return;
+  a += (size_t)b_lo * In;
+  g += (size_t)b_lo * Out;
+  if (coef != nullptr) coef += b_lo;
   extern __shared__ __attribute__((aligned(16))) bf16_t cb_lds[];
   bf16_t (*ldg)[CB_KB][CB_PG] = reinterpret_cast<bf16_t (*)[CB_KB][CB_PG]>(cb_lds);
   bf16_t (*lda)[CB_KB][CB_PA] = reinterpret_cast<bf16_t (*)[CB_KB][CB_PA]>(cb_lds + 2 * CB_KB * CB_PG);
@@ -422,7 +433,8 @@ clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __res
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
         if (m < Out && n < In) {
           float* p = SW + (size_t)m * In + n;
-          *p = accumulate ? *p + acc[i][j][r] : acc[i][j][r];
+          if (split) atomicAdd(p, acc[i][j][r]);
+          else *p = accumulate ? *p + acc[i][j][r] : acc[i][j][r];
         }
       }
   if (do_bias) {
@@ -433,7 +445,8 @@ clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __res
     if (tid < CB_TM && m0 + tid < Out) {
       float v = 0.f;
       for (int r = 0; r < 16; ++r) v += red[r * CB_TM + tid];
-      Sb[m0 + tid] = accumulate ? Sb[m0 + tid] + v : v;
+      if (split) atomicAdd(Sb + m0 + tid, v);
+      else Sb[m0 + tid] = accumulate ? Sb[m0 + tid] + v : v;
     }
   }
 }
@@ -881,8 +894,14 @@ extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && In > 0 && Out > 0, VQAF_E_SHAPE);
   if (dtype == VQAF_BF16) {
-    const dim3 grid((In + CB_TN - 1) / CB_TN, (Out + CB_TM - 1) / CB_TM);
+    dim3 grid((In + CB_TN - 1) / CB_TN, (Out + CB_TM - 1) / CB_TM);
     VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);
+    // few output tiles: split the batch over workgroups (2..8 ways, >= 2 stages each)
+    int splits = 1;
+    const int tiles = (int)(grid.x * grid.y);
+    while (tiles * splits < 128 && splits < 8 && B / (splits * 2) >= 2 * CB_KB) splits *= 2;
+    const int rows_per_split = ((B + splits - 1) / splits + CB_KB - 1) / CB_KB * CB_KB;
+    grid.z = splits;
     const bf16_t* ab = reinterpret_cast<const bf16_t*>(a);
     const bf16_t* gb = reinterpret_cast<const bf16_t*>(g);
     auto vec_of = [](const void* p, int pitch) {
@@ -891,8 +910,12 @@ extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float
       return 1;
     };
     const int vg = vec_of(g, Out), va = vec_of(a, In);
-    hipStream_t st = (hipStream_t)stream;
     const size_t cb_smem = (size_t)2 * CB_KB * (CB_PG + CB_PA) * sizeof(bf16_t);  // 80 KiB
+    hipStream_t st = (hipStream_t)stream;
+    if (splits > 1 && !accumulate) {  // atomics add into the output: start it from zero
+      if (hipMemsetAsync(SW, 0, (size_t)Out * In * 4, st) != hipSuccess) return VQAF_E_LAUNCH;
+      if (Sb != nullptr && hipMemsetAsync(Sb, 0, (size_t)Out * 4, st) != hipSuccess) return VQAF_E_LAUNCH;
+    }
 #define VQAF_CSB(VG, VA)                                                                              \
   do {                                                                                                \
     static bool attr_set = false;                                                                     \
@@ -902,7 +925,7 @@ extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float
       attr_set = true;                                                                                \
     }                                                                                                 \
     hipLaunchKernelGGL((clipped_sum_linear_bf16_kernel<VG, VA>), grid, dim3(DP_THREADS), cb_smem, st, \
-                       ab, gb, coef, B, In, Out, accumulate, SW, Sb);                                 \
+                       ab, gb, coef, B, In, Out, accumulate, SW, Sb, rows_per_split);                 \
   } while (0)
     if (vg == 8 && va == 8) VQAF_CSB(8, 8);
     else if (vg == 2 && va == 8) VQAF_CSB(2, 8);
