@@ -91,9 +91,10 @@ __device__ __forceinline__ void store8_nt(void* base, size_t e, const float (&v)
     r.z = pack_bf16x2(v[4], v[5]); r.w = pack_bf16x2(v[6], v[7]);
     store_nt16(reinterpret_cast<bf16_t*>(base) + e, r);
   } else {
-    float* p = reinterpret_cast<float*>(base) + e;
-    store_nt16(p, u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
-    store_nt16(p + 4, u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])});
+    // f32: a lane's 32 bytes go out as two 16-byte stores, each covering only every other
+    // 16 bytes of a line across the wave; streamed (uncached) that is two partial-line writes
+    // (measured 2.2 TB/s), through the cache the halves merge -- so f32 uses ordinary stores
+    store8<false>(base, e, v);
   }
 }
 
