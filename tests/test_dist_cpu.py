@@ -87,3 +87,68 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     # the summed noise has variance (sigma C)^2: 2 shares of variance 1/2 each
     n = got["noise_total"]
     assert abs(float(n.std()) - 1.0) < 5.0 / n.numel() ** 0.5 + 0.05
+
+
+def _sampler_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    vdist.init_from_env(backend="gloo")
+    from vqa_amd import dp
+    torch.manual_seed(42)  # identically seeded ranks: the case a rank-unaware sampler gets wrong
+    n, bs = 96, 12
+    x, y = gi.normal(1, n, IN), gi.labels(2, n, C)
+    ds = torch.utils.data.TensorDataset(x, y, torch.arange(n))
+    loader = torch.utils.data.DataLoader(ds, batch_size=bs)
+    engine = dp.PrivacyEngine()
+    model = _model()
+    gsm, opt, dl = engine.make_private(module=model, optimizer=torch.optim.SGD(model.parameters(), lr=0.1),
+                                       data_loader=loader, noise_multiplier=1.0, max_grad_norm=1.0,
+                                       poisson_sampling=True, seed=5)
+    assert opt.expected_batch_size == bs  # the logical batch, not bs * world
+    owned = dl.batch_sampler.owned().tolist()
+    steps, total = [], torch.zeros(sum(p.numel() for p in model.parameters()))
+    for batch in dl:
+        idx = [] if batch is None else batch[2].tolist()
+        steps.append(idx)
+        bucket = torch.zeros_like(total)
+        if idx:  # this rank's clipped sums of the samples it drew (the oracle does what the kernels do)
+            _, _, sums, _ = do.dp_step(model, x[idx], y[idx], 1.0, 0.0, bs)
+            bucket = _flat(sums)
+        total += vdist.allreduce_sum_(bucket)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {"owned": owned, "steps": steps})
+    if rank == 0:
+        torch.save({"ranks": gathered, "total": total}, os.path.join(out_dir, "sampler.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_poisson_shards_are_disjoint(tmp_path):
+    """make_private in a process group: rank shards partition the dataset, so no sample enters
+    two ranks' batches in a step and the reduced sum counts every drawn sample once, clipped to C."""
+    world, port = 2, _free_port()
+    mp.spawn(_sampler_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "sampler.pt"), weights_only=False)
+    r0, r1 = got["ranks"]
+    assert not set(r0["owned"]) & set(r1["owned"])
+    assert sorted(r0["owned"] + r1["owned"]) == list(range(96))
+    assert len(r0["steps"]) == len(r1["steps"]) == 8
+    x, y = gi.normal(1, 96, IN), gi.labels(2, 96, C)
+    want = None
+    drawn = 0
+    for s0, s1 in zip(r0["steps"], r1["steps"]):
+        assert not set(s0) & set(s1)
+        assert set(s0) <= set(r0["owned"]) and set(s1) <= set(r1["owned"])
+        assert len(set(s0)) == len(s0) and len(set(s1)) == len(s1)
+        union = s0 + s1
+        drawn += len(union)
+        if union:
+            norms, clip, sums, _ = do.dp_step(_model(), x[union], y[union], 1.0, 0.0, 12)
+            assert float((norms * clip).max()) <= 1.0 + 1e-6  # one sample contributes at most C in total
+            want = _flat(sums) if want is None else want + _flat(sums)
+    assert 96 * 0.5 < drawn < 96 * 1.6  # 8 steps at rate 1/8 draw about one dataset's worth
+    assert r0["steps"] != r1["steps"]
+    # sums of ~100 clipped per-sample gradients in f32, grouped differently on the two sides
+    np.testing.assert_allclose(got["total"].numpy(), want.numpy(), rtol=1e-5,
+                               atol=1e-5 * float(want.abs().max()))

@@ -362,3 +362,211 @@ def test_ghost_clip_equals_separate_kernels(dev):
         for i in range(n):  # rows scaled in place by their sample's coefficient
             want = (g[i].float() * coef[:, None]).to(dt)
             assert torch.equal(g2[i], want), i
+
+
+# ------------------------------------------------------------------ benchmark-sized batches
+CLASSIFIER_LINEARS = [(1024, 2048), (2048, 1024), (1024, 430)]
+
+
+@pytest.mark.parametrize("B", [128, 256, 512, 1024])
+@pytest.mark.parametrize("In,Out", CLASSIFIER_LINEARS)
+def test_clipped_sum_bf16_at_benchmark_batches(dev, B, In, Out):
+    """The bf16 MFMA clipped sum at the batch sizes the DP-SGD step of the benchmark runs
+    (2..16 pipeline stages of 64 rows; the 430-row head splits the batch over blockIdx.z and adds
+    partial tiles with f32 atomics from B = 256 on) against an f64 contraction of the same bf16
+    operands, with the coefficient applied in the kernel and with pre-scaled rows (coef == NULL)."""
+    from vqa_amd._lib import BF16, check, load, ptr, stream_ptr
+    lib, st = load(), stream_ptr(dev)
+    a = gi.normal(31, B, In).bfloat16()
+    g = (gi.normal(32, B, Out) * 1e-2).bfloat16()
+    coef = torch.from_numpy(np.random.default_rng(33).uniform(0.5, 1.5, B).astype(np.float32))
+    ad, gd, cd = a.to(dev), g.to(dev), coef.to(dev)
+    SW = torch.full((Out, In), float("nan"), device=dev)
+    Sb = torch.full((Out,), float("nan"), device=dev)
+    # pre-scaled rows: exact products of bf16 operands, f32 accumulation
+    check(lib.vqaf_clipped_sum_linear(ptr(ad), ptr(gd), None, B, In, Out, BF16, 0, ptr(SW), ptr(Sb), st), "cs")
+    want = g.double().t() @ a.double()
+    wscale = float(want.abs().max())
+    np.testing.assert_allclose(SW.cpu().numpy(), want.numpy(), rtol=1e-5, atol=2e-6 * wscale)
+    sb_want = g.double().sum(0)
+    np.testing.assert_allclose(Sb.cpu().numpy(), sb_want.numpy(), rtol=1e-5, atol=2e-6 * float(sb_want.abs().max()))
+    # micro-batches of 64 rows through the accumulate flag take the one-stage, unsplit path:
+    # both decompositions of the same sum agree to f32 summation-order noise
+    SW2 = torch.zeros(Out, In, device=dev)
+    Sb2 = torch.zeros(Out, device=dev)
+    for lo in range(0, B, 64):
+        check(lib.vqaf_clipped_sum_linear(ptr(ad[lo:lo + 64]), ptr(gd[lo:lo + 64]), None, 64, In, Out, BF16, 1,
+                                          ptr(SW2), ptr(Sb2), st), "cs")
+    np.testing.assert_allclose(SW.cpu().numpy(), SW2.cpu().numpy(), rtol=1e-5, atol=2e-6 * wscale)
+    np.testing.assert_allclose(Sb.cpu().numpy(), Sb2.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    # coefficient applied while staging (coef * g re-rounded to bf16: 2^-9 per element)
+    check(lib.vqaf_clipped_sum_linear(ptr(ad), ptr(gd), ptr(cd), B, In, Out, BF16, 0, ptr(SW), ptr(Sb), st), "cs")
+    wantc = (coef.double()[:, None] * g.double()).t() @ a.double()
+    cscale = float(wantc.abs().max())
+    np.testing.assert_allclose(SW.cpu().numpy(), wantc.numpy(), rtol=1e-2, atol=2e-3 * cscale)
+    assert float((SW.cpu().double() - wantc).norm() / wantc.norm()) < 3e-3
+    np.testing.assert_allclose(Sb.cpu().numpy(), (coef.double()[:, None] * g.double()).sum(0).numpy(),
+                               rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_ghost_clip_at_benchmark_batch(dev, dt):
+    """vqaf_ghost_clip over the five wrapped layers of the classifier at B = 1024 against f64
+    arithmetic on the same stored values, and against the separate norm / coefficient kernels."""
+    import ctypes
+    from vqa_amd._lib import check, dtype_code, load, ptr, stream_ptr
+    lib, st = load(), stream_ptr(dev)
+    B, C_clip = 1024, 1.0
+    layers = [(1, 1024, 2048), (2, 2048, 2048), (1, 2048, 1024), (2, 1024, 1024), (1, 1024, 430)]
+    a = [gi.normal(40 + i, B, L[1]).to(dt) for i, L in enumerate(layers)]
+    # backprops of a mean-reduced loss are O(1/B); a per-sample spread makes some samples clip and some not
+    spread = torch.from_numpy(np.random.default_rng(5).uniform(0.02, 3.0, B).astype(np.float32))[:, None]
+    g = [(gi.normal(50 + i, B, L[2]) * spread * (2e-2 / B / (L[1] ** 0.5))).to(dt) for i, L in enumerate(layers)]
+    sq = torch.zeros(B, dtype=torch.float64)
+    for (k, In, Out), ai, gi_ in zip(layers, a, g):
+        ad_, gd_ = ai.double(), gi_.double()
+        if k == 2:
+            sq += (ad_ * gd_).pow(2).sum(1) + gd_.pow(2).sum(1)
+        else:
+            sq += ad_.pow(2).sum(1) * gd_.pow(2).sum(1) + gd_.pow(2).sum(1)
+    norm_want = B * sq.sqrt()
+    coef_want = B * (C_clip / (norm_want + 1e-6)).clamp(max=1.0)
+    assert 0.2 < float((coef_want < B).double().mean()) < 0.8  # both branches of the clip are exercised
+    ad, gd = [t.to(dev) for t in a], [t.to(dev) for t in g]
+    n = len(layers)
+    pa = (ctypes.c_void_p * n)(*[ptr(t) for t in ad])
+    pg = (ctypes.c_void_p * n)(*[ptr(t) for t in gd])
+    din = (ctypes.c_int * n)(*[L[1] for L in layers])
+    dout = (ctypes.c_int * n)(*[L[2] for L in layers])
+    kd = (ctypes.c_int * n)(*[L[0] for L in layers])
+    coef, norms, sq2 = (torch.empty(B, device=dev) for _ in range(3))
+    check(lib.vqaf_ghost_clip(n, pa, pg, din, dout, kd, B, dtype_code(gd[0]), C_clip, float(B), 1, ptr(coef),
+                              ptr(norms), ptr(sq2), st), "ghost_clip")
+    np.testing.assert_allclose(sq2.cpu().numpy(), sq.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(norms.cpu().numpy(), norm_want.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(coef.cpu().numpy(), coef_want.numpy(), rtol=1e-5)
+    for i in range(n):  # rows scaled in place by their sample's coefficient
+        assert torch.equal(gd[i].cpu(), (g[i].float() * coef.cpu()[:, None]).to(dt)), i
+    # the separate kernels on the unscaled rows
+    gd0 = [t.to(dev) for t in g]
+    sq3 = torch.empty(B, device=dev)
+    for i, (k, In, Out) in enumerate(layers):
+        if k == 2:
+            check(lib.vqaf_ghost_sqnorm_affine(ptr(ad[i]), ptr(gd0[i]), B, Out, dtype_code(gd0[i]), int(i > 0),
+                                               ptr(sq3), st), "aff")
+        else:
+            check(lib.vqaf_ghost_sqnorm_linear(ptr(ad[i]), ptr(gd0[i]), B, In, Out, dtype_code(gd0[i]), k,
+                                               int(i > 0), ptr(sq3), st), "lin")
+    np.testing.assert_allclose(sq3.cpu().numpy(), sq2.cpu().numpy(), rtol=2e-6)
+
+
+def _unambiguous_rows(cpu_m, x, tol=2e-5):
+    """Rows of x whose ReLU inputs all stay clear of zero: a pre-activation within rounding noise
+    of zero may open the gate on one side and not on the other, which changes that sample's
+    gradient by a whole unit's worth -- a property of ReLU, not of either implementation."""
+    keep = torch.ones(x.shape[0], dtype=torch.bool)
+    h = x
+    with torch.no_grad():
+        for layer in cpu_m:
+            if isinstance(layer, nn.ReLU):
+                keep &= h.abs().min(dim=1).values > tol
+            h = layer(h)
+    return keep
+
+
+def test_dp_step_f32_batch_256_vs_chunked_oracle(dev):
+    """One whole DP step of the BASELINE classifier at B = 256 (4 pipeline stages, split head)
+    against the per-sample-gradient oracle evaluated in chunks of 32 samples; the clip norm is the
+    median per-sample norm, so both branches of the clip are taken."""
+    from vqa_amd import dp
+    in_dim, hidden, C, B, sigma, E = 1024, 1024, 430, 256, 1.0, 1024
+    cpu_m = _classifier(500, in_dim, hidden, C)
+    x, y = gi.normal(61, B + 64, in_dim), gi.labels(62, B + 64, C)
+    keep = _unambiguous_rows(cpu_m, x)
+    assert int(keep.sum()) >= B
+    x, y = x[keep][:B].contiguous(), y[keep][:B].contiguous()
+    norms0, _, _, _ = do.dp_step(cpu_m, x[:32], y[:32], 1.0, 0.0, E)
+    max_norm = float(norms0.median())
+    norms, clips, sums = [], [], None
+    for lo in range(0, B, 32):
+        n_, c_, s_, _ = do.dp_step(cpu_m, x[lo:lo + 32], y[lo:lo + 32], max_norm, 0.0, E)
+        norms.append(n_)
+        clips.append(c_)
+        sums = s_ if sums is None else {k: sums[k].double() + s_[k].double() for k in s_}
+    norms, clips = torch.cat(norms), torch.cat(clips)
+    assert 0.2 < float((clips < 1).double().mean()) < 0.8
+    z = {n: gi.normal(2000 + i, *p.shape) for i, (n, p) in enumerate(cpu_m.named_parameters())}
+
+    gpu_m = _classifier(500, in_dim, hidden, C).to(dev)
+    gsm = dp.GradSampleModule(gpu_m)
+    opt = dp.DPOptimizer(torch.optim.SGD(gpu_m.parameters(), lr=0.1), gsm, noise_multiplier=sigma,
+                         max_grad_norm=max_norm, expected_batch_size=E)
+    nn.CrossEntropyLoss()(gsm(x.to(dev)), y.to(dev)).backward()
+    S = opt.clip_and_accumulate().clone()
+    np.testing.assert_allclose(opt.last_norms.cpu().numpy(), norms.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(opt.last_clip.cpu().numpy(), clips.numpy(), rtol=1e-5)
+    got = _flat_to_named(opt, gsm, S)
+    for n, want in sums.items():
+        scale = max(1e-6, float(want.abs().max()))
+        np.testing.assert_allclose(got["_module." + n].numpy(), want.float().numpy(), rtol=1e-5, atol=4e-6 * scale,
+                                   err_msg=n)
+    flat_z = torch.zeros(opt._numel)
+    for (o, numel, shape), (n, p) in zip(opt.flat_noise_layout(), cpu_m.named_parameters()):
+        flat_z[o:o + numel] = z[n].reshape(-1)
+    opt.add_noise_and_scale(noise=flat_z.to(dev))
+    for n, p in gsm.named_parameters():
+        k = n.replace("_module.", "")
+        want = ((sums[k].double() + sigma * max_norm * z[k].double()) / E).float()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want.numpy(), rtol=1e-5, atol=4e-6 * float(want.abs().max()),
+                                   err_msg=n)
+
+
+def test_dp_step_bf16_batch_1024_bounds_and_direction(dev):
+    """bf16 tapes at the benchmark's batch: every sample's clipped gradient, as the clipped-sum
+    kernels consume it (rows re-rounded to bf16 after scaling), has norm <= C; the sums agree in
+    direction and size with the f64 contraction of the recorded tapes."""
+    from vqa_amd import dp
+    in_dim, hidden, C, B = 1024, 1024, 430, 1024
+    gpu_m = _classifier(600, in_dim, hidden, C).to(dev)
+    gsm = dp.GradSampleModule(gpu_m)
+    opt = dp.DPOptimizer(torch.optim.SGD(gpu_m.parameters(), lr=0.1), gsm, noise_multiplier=0.0,
+                         max_grad_norm=1.0, expected_batch_size=B)
+    x, y = gi.normal(71, B, in_dim), gi.labels(73, B, C)
+    logits = gsm(x.to(dev).bfloat16())
+    nn.CrossEntropyLoss()(logits.float(), y.to(dev)).backward()
+    tapes = [(t.kind, t.module, t.a.detach().clone(), t.g.detach().clone()) for t in gsm.tapes]
+    keep_g = [t.g for t in gsm.tapes]  # scaled in place by the step
+
+    def sample_norms(rows):  # per-sample gradient norm of the tapes with the given backprop rows, f64
+        sq = torch.zeros(B, dtype=torch.float64)
+        for (kind, m, a, _g0), g in zip(tapes, rows):
+            a_, g_ = a.double().cpu(), g.double().cpu()
+            sq += (a_.pow(2).sum(1) * g_.pow(2).sum(1) if kind == "linear" else (a_ * g_).pow(2).sum(1)) \
+                + g_.pow(2).sum(1)
+        return sq.sqrt()
+
+    true_norms = B * sample_norms([t[3] for t in tapes])
+    max_norm = float(true_norms.median())  # half of the samples clip
+    opt.max_grad_norm = max_norm
+    S = opt.clip_and_accumulate()
+    np.testing.assert_allclose(opt.last_norms.cpu().numpy(), true_norms.numpy(), rtol=1e-5)
+    coef = (opt.last_clip * B).double().cpu()
+    names = {id(p): n for n, p in gsm.named_parameters()}
+    for (kind, m, a, g0), gs in zip(tapes, keep_g):
+        assert gs.dtype == torch.bfloat16
+        a_, g_ = a.double().cpu(), gs.double().cpu()  # what the clipped sums contract
+        want_w = g_.t() @ a_ if kind == "linear" else (a_ * g_).sum(0)
+        o = opt._offsets[id(m.weight)]
+        got_w = S[o:o + m.weight.numel()].view_as(m.weight).double().cpu()
+        np.testing.assert_allclose(got_w.numpy(), want_w.numpy(), rtol=1e-4, atol=1e-5 * float(want_w.abs().max()),
+                                   err_msg=names[id(m.weight)])
+        # against the unrounded product coef * g (bf16 bar)
+        exact = (coef[:, None] * g0.double().cpu())
+        ref_w = exact.t() @ a_ if kind == "linear" else (a_ * exact).sum(0)
+        rel = float((got_w - ref_w).norm() / ref_w.norm())
+        assert rel < 1e-2, (names[id(m.weight)], rel)
+    clipped_norm = sample_norms(keep_g)
+    assert float(clipped_norm.max()) <= max_norm, (float(clipped_norm.max()), max_norm)
+    assert float(clipped_norm.max()) > 0.99 * max_norm  # the margin is small
+    frac_clipped = float((opt.last_clip < 0.999).double().mean())
+    assert 0.3 < frac_clipped < 0.7, frac_clipped

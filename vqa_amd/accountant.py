@@ -149,23 +149,25 @@ class RDPAccountant:
 
 def get_noise_multiplier(*, target_epsilon: float, target_delta: float, sample_rate: float, steps: int,
                          epsilon_tolerance: float = 0.01) -> float:
-    """Smallest sigma (bisection) whose epsilon after `steps` steps is <= target_epsilon."""
+    """Noise multiplier whose epsilon after `steps` steps lands within `epsilon_tolerance` below
+    target_epsilon.  The bracketing and bisection follow Opacus 1.4.0's search step for step
+    (upper bracket 10 doubled BEFORE its first evaluation, loop on the epsilon gap only, upper
+    end returned), so the same target yields the same sigma; parity unpinned (Opacus absent)."""
     def eps_of(sigma: float) -> float:
         return rdp_to_epsilon(compute_rdp(sample_rate, sigma, steps), DEFAULT_ALPHAS, target_delta)[0]
 
-    lo, hi = 0.0, 10.0
-    while eps_of(hi) > target_epsilon:
-        hi *= 2.0
-        if hi > 1e6:
+    eps_high = math.inf
+    sigma_low, sigma_high = 0.0, 10.0
+    while eps_high > target_epsilon:
+        sigma_high *= 2.0
+        eps_high = eps_of(sigma_high)
+        if sigma_high > 1e6:
             raise ValueError("the privacy budget is too low")
-    while True:
-        mid = (lo + hi) / 2.0
-        e = eps_of(mid) if mid > 0 else math.inf
-        if e < target_epsilon:
-            hi = mid
-            if target_epsilon - e <= epsilon_tolerance:
-                return hi
+    while target_epsilon - eps_high > epsilon_tolerance:
+        sigma = (sigma_low + sigma_high) / 2.0
+        eps = eps_of(sigma)
+        if eps < target_epsilon:
+            sigma_high, eps_high = sigma, eps
         else:
-            lo = mid
-        if hi - lo < 1e-6:
-            return hi
+            sigma_low = sigma
+    return sigma_high

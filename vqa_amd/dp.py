@@ -249,6 +249,7 @@ class DPOptimizer:
         self._rng = None
         self._seed = seed
         self._P = self._M = self._V = self._shadow = self._step = None
+        self._pending_state = None  # optimizer state loaded before the fused buckets exist
         self._use_fused = False
         self.last_norms = None
         self._last_coef, self._last_scale = None, 1.0
@@ -274,7 +275,35 @@ class DPOptimizer:
         return self.original_optimizer.state_dict()
 
     def load_state_dict(self, sd):
+        """Restores the wrapped optimizer's state; when the fused step is (or will be) in use the
+        loaded moments and step count are copied into its flat buckets, so a resumed run continues
+        from them instead of from zero."""
         self.original_optimizer.load_state_dict(sd)
+        state = self.original_optimizer.state
+        if not any(len(state.get(p, {})) for p in self.params):
+            return
+        self._pending_state = {id(p): dict(state[p]) for p in self.params if len(state.get(p, {}))}
+        if self._P is not None:
+            self._adopt_loaded_state()
+
+    @torch.no_grad()
+    def _adopt_loaded_state(self):
+        pend, self._pending_state = self._pending_state, None
+        if not pend:
+            return
+        step = 0
+        for p in self.params:
+            st = pend.get(id(p))
+            if st is None:
+                continue
+            o = self._offsets[id(p)]
+            self._M[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self._V[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            step = max(step, int(float(st["step"])))
+        self._step[1] = step
+        # the fused kernel owns the state from here on (state_dict() publishes it back)
+        for p in self.params:
+            self.original_optimizer.state.pop(p, None)
 
     def zero_grad(self, set_to_none: bool = False):
         # Parameter .grad tensors are views of the flat buffer and are overwritten by every
@@ -302,6 +331,13 @@ class DPOptimizer:
             world, rank = self._world()
             seed = self._seed if self._seed is not None else torch.initial_seed()
             self._rng = ops.PhiloxState(device, seed=seed, stream_salt=1 + rank)
+        else:
+            # an outside model.zero_grad(set_to_none=True) drops the views; without them the
+            # wrapped optimizer would silently skip those parameters
+            for p in self.params:
+                if p.grad is None:
+                    o = self._offsets[id(p)]
+                    p.grad = self._grad[o:o + p.numel()].view_as(p)
         return self._S, self._grad
 
     def _fusable(self) -> bool:
@@ -313,7 +349,11 @@ class DPOptimizer:
         if any(g.get("amsgrad") or g.get("maximize") or isinstance(g["lr"], torch.Tensor)
                for g in opt.param_groups):
             return False
-        return all(p.dtype == torch.float32 for p in self.params) and len(opt.state) == 0
+        if not all(p.dtype == torch.float32 for p in self.params):
+            return False
+        # a state loaded before the first step is adopted by the fused buckets; any other
+        # pre-existing state (steps already taken by the wrapped optimizer itself) is not
+        return len(opt.state) == 0 or self._pending_state is not None
 
     def _fused_buffers(self, device):
         """Flat parameter / moment buckets; every Parameter becomes a view of the flat bucket
@@ -337,6 +377,7 @@ class DPOptimizer:
                     lookup[view.data_ptr()] = self._shadow[o:o + p.numel()].view_as(p)
                 self._shadow.copy_(self._P)
             self.module.shadow = lookup
+            self._adopt_loaded_state()
 
     @torch.no_grad()
     def _fused_apply(self, noise: Optional[torch.Tensor] = None):
@@ -401,6 +442,13 @@ class DPOptimizer:
             t.g = g
         # a mean-reduced loss hands back gradients divided by B; undo it (Opacus: loss_reduction)
         scale = float(B) if self.module.loss_reduction == "mean" else 1.0
+        # bf16 tapes: the clipped rows coef * g are re-rounded to bf16 on their way into the MFMA
+        # (up to 2^-9 relative per element), which could lift a clipped sample's norm just above
+        # C.  Clipping to C (1 - 2^-8) keeps every sample's contribution <= C after the rounding,
+        # so the sensitivity the accountant assumes holds exactly.
+        max_norm = self.max_grad_norm
+        if any(t.g.dtype == torch.bfloat16 for t in tapes):
+            max_norm *= 1.0 - 2.0 ** -8
         coef = torch.empty(B, dtype=torch.float32, device=dev)
         norms = torch.empty(B, dtype=torch.float32, device=dev)
         n = len(tapes)
@@ -417,7 +465,7 @@ class DPOptimizer:
             # the same launch scales every recorded backprop row by its clip coefficient in place
             # (the tapes are dead after this step), so the sums below are plain contractions
             check(lib.vqaf_ghost_clip(n, pa, pg, din, dout, kind, B, dtype_code(tapes[0].g),
-                                      self.max_grad_norm, scale, 1, ptr(coef), ptr(norms), None, st),
+                                      max_norm, scale, 1, ptr(coef), ptr(norms), None, st),
                   "vqaf_ghost_clip")
             prescaled = True
         else:
@@ -431,7 +479,7 @@ class DPOptimizer:
                 else:
                     check(lib.vqaf_ghost_sqnorm_affine(ptr(a), ptr(g), B, g.shape[1], dtype_code(g),
                                                        int(i > 0), ptr(sq), st), "vqaf_ghost_sqnorm_affine")
-            check(lib.vqaf_clip_coef(ptr(sq), B, self.max_grad_norm, scale, ptr(coef), ptr(norms), st),
+            check(lib.vqaf_clip_coef(ptr(sq), B, max_norm, scale, ptr(coef), ptr(norms), st),
                   "vqaf_clip_coef")
         self.last_norms, self._last_coef, self._last_scale = norms, coef, scale
         for t in tapes:
@@ -509,6 +557,21 @@ class DPOptimizer:
             t.g = None
         return result
 
+    @torch.no_grad()
+    def empty_step(self, device: Optional[torch.device] = None):
+        """The step for an EMPTY Poisson batch: clipped sums of zero, so the update is noise only.
+        Opacus takes (and accounts for) this step too; skipping it would make the number of
+        accounted steps depend on the sampled data.  In a process group a rank whose shard came
+        up empty still joins the all-reduce through this call."""
+        self._buffers(self._S.device if self._S is not None else (device or self.params[0].device))
+        self._S.zero_()
+        world, _ = self._world()
+        self._use_fused = self._fusable() or self._P is not None
+        if not (self._use_fused and world == 1):
+            self._noise_scale_local(None)
+        self.reduce_step()
+        return self.apply_step()
+
     def pre_step(self, noise: Optional[torch.Tensor] = None):
         self.clip_and_accumulate()
         self.add_noise_and_scale(noise)
@@ -545,13 +608,54 @@ class PoissonBatchSampler(torch.utils.data.Sampler):
             yield mask.nonzero(as_tuple=False).reshape(-1).tolist()
 
 
+class DistributedPoissonBatchSampler(torch.utils.data.Sampler):
+    """Poisson sampling in a process group (Opacus DistributedUniformWithReplacementSampler): the
+    dataset is permuted with a seed every rank shares, rank r owns the strided shard
+    perm[r::world] -- shards are DISJOINT, so a sample can enter at most one rank's batch and its
+    total contribution to the all-reduced sum stays <= C -- and each step includes every owned
+    sample independently with probability sample_rate from a rank-private generator.  Over all
+    ranks a step is exactly one Poisson sample of the whole dataset at rate sample_rate, which is
+    what the accountant is stepped with."""
+
+    def __init__(self, num_samples: int, sample_rate: float, rank: int, world: int,
+                 steps: Optional[int] = None, shuffle_seed: int = 0, generator: Optional[torch.Generator] = None):
+        self.total, self.sample_rate = int(num_samples), float(sample_rate)
+        self.rank, self.world = int(rank), int(world)
+        self.steps = int(steps) if steps is not None else int(round(1.0 / sample_rate))
+        self.shuffle_seed, self.epoch = int(shuffle_seed), 0
+        if generator is None:
+            generator = torch.Generator().manual_seed((torch.initial_seed() + 7919 * (self.rank + 1)) % (1 << 63))
+        self.generator = generator
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def owned(self) -> torch.Tensor:
+        g = torch.Generator().manual_seed(self.shuffle_seed + self.epoch)
+        return torch.randperm(self.total, generator=g)[self.rank::self.world]
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        mine = self.owned()
+        for _ in range(self.steps):
+            mask = torch.rand(mine.numel(), generator=self.generator) < self.sample_rate
+            yield mine[mask].tolist()
+
+
 class DPDataLoader(torch.utils.data.DataLoader):
     """DataLoader over the same dataset with Poisson batches (make_private(poisson_sampling=True))."""
 
     @classmethod
-    def from_data_loader(cls, dl: torch.utils.data.DataLoader, generator=None):
+    def from_data_loader(cls, dl: torch.utils.data.DataLoader, generator=None, rank: int = 0, world: int = 1,
+                         shuffle_seed: int = 0):
         sample_rate = 1.0 / len(dl)
-        sampler = PoissonBatchSampler(len(dl.dataset), sample_rate, steps=len(dl), generator=generator)
+        if world > 1:
+            sampler = DistributedPoissonBatchSampler(len(dl.dataset), sample_rate, rank, world, steps=len(dl),
+                                                     shuffle_seed=shuffle_seed, generator=generator)
+        else:
+            sampler = PoissonBatchSampler(len(dl.dataset), sample_rate, steps=len(dl), generator=generator)
         collate = dl.collate_fn
 
         def collate_skip_empty(batch):
@@ -583,20 +687,28 @@ class PrivacyEngine:
             gsm = module
         else:
             gsm = GradSampleModule(module, batch_first=batch_first, loss_reduction=loss_reduction)
-        if data_loader is not None:
-            sample_rate = 1.0 / len(data_loader)
-            expected = int(len(data_loader.dataset) * sample_rate)
-            loader = DPDataLoader.from_data_loader(data_loader) if poisson_sampling else data_loader
-        else:
-            sample_rate, expected, loader = None, None, None
-        world = 1
+        if data_loader is None:
+            raise ValueError("data_loader is required to derive sample_rate and expected_batch_size")
+        world, rank = 1, 0
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
-            world = dist.get_world_size(process_group)
-        if expected is None:
-            raise ValueError("data_loader is required to derive sample_rate and expected_batch_size")
+            world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        sample_rate = 1.0 / len(data_loader)
+        # the LOGICAL expected batch: one Poisson sample of the whole dataset per step, drawn
+        # jointly by all ranks from disjoint shards
+        expected = int(len(data_loader.dataset) * sample_rate)
+        if poisson_sampling:
+            loader = DPDataLoader.from_data_loader(data_loader, rank=rank, world=world,
+                                                   shuffle_seed=int(seed or 0))
+        elif world > 1:
+            # without Poisson sampling the caller's loader decides what each rank sees; identical
+            # loaders on every rank would count each sample world times against one noise draw
+            raise ValueError("with several ranks make_private needs poisson_sampling=True (rank-disjoint "
+                             "Poisson shards); a caller-sharded fixed loader is not accounted for here")
+        else:
+            loader = data_loader
         dp_opt = DPOptimizer(optimizer, gsm, noise_multiplier=noise_multiplier,
-                             max_grad_norm=max_grad_norm, expected_batch_size=expected * world,
+                             max_grad_norm=max_grad_norm, expected_batch_size=expected,
                              seed=seed, process_group=process_group)
         self.sample_rate = sample_rate
         dp_opt.attach_step_hook(

@@ -33,6 +33,12 @@ def train(model: nn.Module, train_loader, optimizer, criterion, device, model_ty
     n = 0
     for batch in train_loader:
         if batch is None:  # an empty Poisson-sampled batch
+            # Opacus still takes (and accounts for) the noise-only step; in a process group the
+            # other ranks are waiting in the all-reduce
+            if split and hasattr(optimizer['classifier'], 'empty_step'):
+                optimizer['classifier'].empty_step(device)
+            elif hasattr(optimizer, 'empty_step'):
+                optimizer.empty_step(device)
             continue
         images, ids, mask, answers = _batch(batch, device)
         if split:                                   # utils/src.py:66-70
