@@ -11,7 +11,10 @@
  *   - return 0 on success, a negative VQAF_E_* code otherwise; never throw, never exit;
  *   - every pointer is a DEVICE pointer unless the name ends in _host;
  *   - tensors are dense row-major; the caller owns every buffer, workspaces included;
- *     the library allocates nothing and keeps no state between calls;
+ *     the library allocates nothing.  Between calls it keeps only read-mostly process state:
+ *     tuning knobs read once from the environment (VQAF_HS_TOKB, VQAF_GM_LPR), a per-kernel
+ *     "dynamic LDS limit raised" flag, and the per-device address of the fixed scratch array of
+ *     vqaf_score_noalloc -- all initialised thread-safely on first use;
  *   - work is only enqueued on `stream` (a hipStream_t passed as void*); no entry point
  *     synchronises with the host, so all of them may be captured into a HIP graph;
  *   - `dtype` is the storage type of token / activation tensors (VQAF_F32 or VQAF_BF16);
@@ -36,7 +39,8 @@ enum vqaf_status {
   VQAF_E_DTYPE = -2,  /* dtype code is not VQAF_F32 / VQAF_BF16 */
   VQAF_E_ALIGN = -3,  /* a pointer or row pitch is not 16-byte aligned */
   VQAF_E_LAUNCH = -4, /* the HIP runtime refused the launch (hipGetLastError != 0) */
-  VQAF_E_NULL = -5    /* a required pointer is NULL */
+  VQAF_E_NULL = -5,   /* a required pointer is NULL */
+  VQAF_E_SCRATCH = -6 /* the sizes need more than the fixed device scratch of a *_noalloc entry point */
 };
 
 enum vqaf_dtype { VQAF_F32 = 0, VQAF_BF16 = 1 };
@@ -107,6 +111,23 @@ size_t vqaf_score_workspace_bytes(int B, int N, int D, int H);
 int vqaf_score(const void* q, const void* seq, const void* in_proj_weight,
                const void* in_proj_bias, int B, int N, int D, int H, int dtype, int w_dtype,
                void* workspace, size_t workspace_bytes, float* w, vqaf_stream_t stream);
+
+/* vqaf_score for callers that cannot allocate device memory and have no workspace to hand over
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
+ * no counterpart in the reference.  Same arithmetic and same results as vqaf_score; qproj, u and
+ * s live in a fixed VQAF_SCORE_SCRATCH_BYTES array inside the library's code object (one copy
+ * per GPU, held until the process ends).  The call allocates and frees nothing.
+ *   - sizes with vqaf_score_workspace_bytes(B,N,D,H) > VQAF_SCORE_SCRATCH_BYTES are refused with
+ *     VQAF_E_SCRATCH before any device work (32 MiB covers B=1024, N=197 and B=512, N=577 at
+ *     D=512, H=8);
+ *   - the device that owns `stream` must be current; the first call on a device resolves the
+ *     array's address (make that call outside stream capture);
+ *   - every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams,
+ *     two threads) race on it.  Calls on one stream are ordered and safe. */
+#define VQAF_SCORE_SCRATCH_BYTES (32u << 20)
+int vqaf_score_noalloc(const void* q, const void* seq, const void* in_proj_weight,
+                       const void* in_proj_bias, int B, int N, int D, int H, int dtype, int w_dtype,
+                       float* w, vqaf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Keep-index selection.  Replaces torch.topk(attn_weights, k) (utils/fusion.py:44) and

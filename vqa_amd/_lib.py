@@ -65,6 +65,7 @@ SIGNATURES = {
     "vqaf_score_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "vqaf_score": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t,
                            _P, _P]),
+    "vqaf_score_noalloc": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "vqaf_topk": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_adv_swap": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "vqaf_adv_swap_random": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),

@@ -7,6 +7,8 @@
 // i.e. two row-norm passes plus one (Out x B) x (B x In) GEMM whose contraction index is the
 // batch.  That GEMM runs on the matrix cores: operands are converted to f32 while they are
 // staged, so the f32 path is exact f32 (v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain).
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -918,12 +920,11 @@ extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float
     }
 #define VQAF_CSB(VG, VA)                                                                              \
   do {                                                                                                \
-    static bool attr_set = false;                                                                     \
-    if (!attr_set) {                                                                                  \
+    static std::once_flag attr_once;                                                                  \
+    std::call_once(attr_once, [&] {                                                                   \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&clipped_sum_linear_bf16_kernel<VG, VA>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_smem);            \
-      attr_set = true;                                                                                \
-    }                                                                                                 \
+    });                                                                                               \
     hipLaunchKernelGGL((clipped_sum_linear_bf16_kernel<VG, VA>), grid, dim3(DP_THREADS), cb_smem, st, \
                        ab, gb, coef, B, In, Out, accumulate, SW, Sb, rows_per_split);                 \
   } while (0)
@@ -1063,6 +1064,7 @@ extern "C" const char* vqaf_status_string(int status) {
     case VQAF_E_ALIGN: return "pointer or row pitch not 16-byte aligned";
     case VQAF_E_LAUNCH: return "HIP launch failed";
     case VQAF_E_NULL: return "required pointer is NULL";
+    case VQAF_E_SCRATCH: return "sizes exceed the fixed device scratch of this entry point (use the variant that takes a workspace)";
     default: return "unknown status";
   }
 }

@@ -13,6 +13,9 @@
 // butterfly, instead of H full 6-step reductions.
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -438,4 +441,61 @@ extern "C" int vqaf_score(const void* q, const void* seq, const void* in_proj_we
   rc = vqaf_head_scores(seq, u, B, N, D, H, dtype, s, stream);
   if (rc != VQAF_OK) return rc;
   return vqaf_attn_weights(s, B, N, H, w, stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// vqaf_score without a caller workspace and without any allocation: the three intermediate
+// buffers (qproj, u, s) live in a file-scope device array that every GPU holds from the moment
+// the code object is loaded until the process ends.
+//
+// `score_scratch` names the array in DEVICE code only; in host code the same identifier is a
+// host-side stand-in whose address means nothing to a kernel.  The device address is asked for
+// once per device (with that device current) and kept; host code below uses only that pointer.
+// ---------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char score_scratch[VQAF_SCORE_SCRATCH_BYTES];
+
+namespace {
+constexpr int SCRATCH_MAX_DEVICES = 64;
+std::atomic<unsigned char*> g_scratch_ptr[SCRATCH_MAX_DEVICES];
+std::mutex g_scratch_mu;
+
+// Device address of score_scratch on the CURRENT device (each GPU has its own copy at its own
+// address).  The first call on a device resolves the symbol; later calls are one atomic load.
+int scratch_on_current_device(unsigned char** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCRATCH_MAX_DEVICES) return VQAF_E_LAUNCH;
+  unsigned char* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (p == nullptr) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    p = g_scratch_ptr[dev].load(std::memory_order_relaxed);
+    if (p == nullptr) {
+      void* addr = nullptr;
+      if (hipGetSymbolAddress(&addr, HIP_SYMBOL(score_scratch)) != hipSuccess || addr == nullptr) {
+        (void)hipGetLastError();
+        return VQAF_E_LAUNCH;
+      }
+      p = reinterpret_cast<unsigned char*>(addr);
+      g_scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+  }
+  *out = p;
+  return VQAF_OK;
+}
+}  // namespace
+
+extern "C" int vqaf_score_noalloc(const void* q, const void* seq, const void* in_proj_weight,
+                                  const void* in_proj_bias, int B, int N, int D, int H, int dtype,
+                                  int w_dtype, float* w, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(w != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(B > 0 && N > 0 && D > 0 && H > 0, VQAF_E_SHAPE);
+  // sizes are checked on the host before anything touches the device
+  VQAF_REQUIRE(vqaf_score_workspace_bytes(B, N, D, H) <= (size_t)VQAF_SCORE_SCRATCH_BYTES, VQAF_E_SCRATCH);
+  unsigned char* ws = nullptr;
+  const int rc = scratch_on_current_device(&ws);
+  if (rc != VQAF_OK) return rc;
+  // every byte of qproj, u and s that a kernel reads is written earlier in this same call, so
+  // nothing left in the array by the previous call needs clearing
+  return vqaf_score(q, seq, in_proj_weight, in_proj_bias, B, N, D, H, dtype, w_dtype, ws,
+                    (size_t)VQAF_SCORE_SCRATCH_BYTES, w, stream);
 }
