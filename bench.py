@@ -8,15 +8,27 @@ COCO-QA-shaped inputs already resident in HBM (encoders are outside the hot path
 zero_grad -> CoAttention(pruning, keep 0.5, adversarial mixing) forward -> classifier forward ->
 mean CE -> backward (classifier input gradients, fusion input gradients) -> per-sample norms,
 clip (C = 1.0), clipped sums, Gaussian noise (sigma = 1.0), RCCL all-reduce, AdamW step.
-At N = 1 this is BASELINE.json configs[2] (logical batch 1024) on one GPU.  For N > 1 the default
-keeps the per-GPU batch at 1024 (weak scaling: logical batch 1024*N, `value` = all samples / time);
-`--scaling strong` shards the literal logical batch 1024 instead, and an N > 1 run also reports that
-sharded configuration under "strong_scaling_1024" so both readings of configs[2] are measured.
 
-Rank 0 prints ONE JSON line: whole-job samples/s plus a `roofline` object for the prune+mix
-kernel (timed live with stream events inside the timed region), a `cpu_baseline` object (the
-oracle, i.e. the reference's op sequence, timed on the host cores on a bounded sample) and the
-prune+mix GB/s sweep of configs[3].
+The workload is BASELINE.json configs[2]: logical batch 1024, sharded 1024/N per GPU (`--scaling
+strong`, the default; at N = 1 the whole batch sits on one GPU).  An N > 1 run also measures the
+weak-scaling variant (1024 per GPU, logical batch 1024*N) and reports it under
+"weak_scaling_1024_per_gpu"; `--scaling weak` swaps the two.
+
+Launch path: the step is captured into HIP graphs (one per rotating input set).  With several
+ranks the collective stays outside the graphs: graph(local work) -> eager RCCL all-reduce ->
+graph(update).  `--eager` launches every kernel from Python instead.
+
+Rank 0 prints ONE JSON line: whole-job samples/s plus
+  roofline      the pooled prune+mix kernel: algorithmic bytes / mean kernel time, against the
+                8 TB/s spec peak and against a device-copy rate measured in the same run.  Kernel
+                time comes from stream events on the launch stream around that one launch.  ROCm
+                refuses event records inside a captured graph ("External events are disallowed"),
+                so when the timed region replays graphs the events bracket the same kernel in the
+                same number of eagerly launched steps run right AFTER the timed region
+                ("kernel_timing" says which of the two applies);
+  mfma          the bf16 MFMA clipped-sum kernels timed the same way: TFLOP/s and fraction of 2.5 PF;
+  cpu_baseline  the oracle (the reference's op sequence) on the host cores, bounded sample;
+  prune_mix_cfg4  the module-boundary prune+mix op of configs[3] (B = 128, N = 577, keep sweep).
 """
 from __future__ import annotations
 
@@ -33,6 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak; the measured copy ceiling is ~6.3 TB/s
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 
 LOGICAL_BATCH = 1024
 N_VIS, N_TXT, D, C = 197, 30, 512, 430
@@ -45,14 +58,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=LOGICAL_BATCH,
-                    help="per-GPU batch (weak scaling) or logical whole-job batch (strong scaling)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+                    help="logical whole-job batch (strong scaling) or per-GPU batch (weak scaling)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graph)")
-    ap.add_argument("--graph-multi", action="store_true",
-                    help="with N > 1 also replay the two compute phases as HIP graphs around the eager "
-                         "RCCL all-reduce (default for N > 1 is eager launches: the graph + collective "
-                         "combination could not be validated on a one-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=64)
@@ -60,24 +69,46 @@ def parse():
 
 
 class Probe:
-    """Stream-event pairs around one named kernel launch (torch's current stream is the stream
-    the C ABI launches on)."""
+    """Stream-event pairs around named kernel launches (torch's current stream is the stream the
+    C ABI launches on).  `names` = the launches to time; a name ending in ':' matches by prefix."""
 
-    def __init__(self, name):
-        self.name, self.pairs, self.enabled, self._open = name, [], False, None
+    def __init__(self, *names):
+        self.names, self.pairs, self.enabled, self._open = names, {}, False, {}
+
+    def _match(self, name):
+        return any(name == n or (n.endswith(":") and name.startswith(n)) for n in self.names)
 
     def __call__(self, name, phase):
-        if not self.enabled or name != self.name:
+        if not self.enabled or not self._match(name):
             return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         if phase == "begin":
-            self._open = ev
+            self._open[name] = ev
         else:
-            self.pairs.append((self._open, ev))
+            self.pairs.setdefault(name, []).append((self._open.pop(name), ev))
 
-    def mean_ms(self):
-        return sum(a.elapsed_time(b) for a, b in self.pairs) / max(1, len(self.pairs))
+    def mean_ms(self, name):
+        pairs = self.pairs.get(name, [])
+        return sum(a.elapsed_time(b) for a, b in pairs) / max(1, len(pairs))
+
+
+def copy_rate_gbs(dev):
+    """Device-to-device copy rate of this GPU in this run (read + written bytes / time): the
+    practical ceiling a streaming kernel can be held against."""
+    n = 256 << 20
+    src = torch.empty(n, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = [torch.empty_like(src) for _ in range(2)]
+    for d in dst:
+        d.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for r in range(reps):
+        dst[r & 1].copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * reps / e0.elapsed_time(e1) / 1e6
 
 
 def build_job(dev, local_b, dtype, rank, logical_b=LOGICAL_BATCH):
@@ -128,12 +159,23 @@ def make_step(fus, gsm, opt, main_opt, sets):
         opt.local_step()
         return loss
 
+    # Ranks that share one device (the two-rank rehearsal on a one-GPU box) drain the launch
+    # stream before the collective: once a process has replayed a HIP graph, a side stream parked
+    # on an event of the launch stream is never released while two processes time-share the GPU
+    # (measured; with one process per GPU the same hand-off completes).
+    shared_device = os.environ.get("VQAF_SINGLE_DEVICE") == "1"
+
+    def reduce():
+        if shared_device:
+            torch.cuda.current_stream().synchronize()
+        opt.reduce_step()
+
     def step(i):
         local(i)
-        opt.reduce_step()
+        reduce()
         opt.apply_step()
 
-    step.local, step.reduce, step.apply = local, opt.reduce_step, opt.apply_step
+    step.local, step.reduce, step.apply = local, reduce, opt.apply_step
     return step
 
 
@@ -175,7 +217,11 @@ def cpu_baseline(sample):
     from oracle import dp_oracle as do
     from oracle import fusion_oracle as fo
     from oracle import inputs as gi
-    threads = min(os.cpu_count() or 1, 16)
+    # the GPU box grants a one-GPU job 16 host CPUs and exports OMP_NUM_THREADS accordingly
+    # (os.cpu_count() there reports the whole machine); elsewhere every visible core is used
+    host_cpus = os.cpu_count() or 1
+    threads = int(os.environ.get("OMP_NUM_THREADS", host_cpus))
+    threads = max(1, min(threads, host_cpus))
     torch.set_num_threads(threads)
     B = sample
     v_seq, v_global = gi.tokens(1, B, N_VIS)
@@ -199,17 +245,21 @@ def cpu_baseline(sample):
         fused.backward(f.grad)  # input gradients of the fusion
         do.dp_step(cls, fused.detach(), y, 1.0, 1.0, LOGICAL_BATCH)
 
-    one()
-    reps, t0 = 0, time.perf_counter()
-    while reps < 3 or time.perf_counter() - t0 < 10.0:
+    for _ in range(2):
         one()
-        reps += 1
-        if time.perf_counter() - t0 > 30.0:
+    times, t_all = [], time.perf_counter()
+    while len(times) < 5 or time.perf_counter() - t_all < 10.0:
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > 30.0:
             break
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": round(B / dt, 2), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} steps of batch {B} (same shapes; fp32; oracle = reference op sequence, "
-                      f"per-sample grads by vmap)"}
+    times.sort()
+    dt = times[len(times) // 2]
+    return {"value": round(B / dt, 2), "unit": "samples/s", "cores": threads, "host_cpus": host_cpus,
+            "kind": "port",
+            "sample": f"median of {len(times)} steps of batch {B} after 2 warm-ups (same shapes; fp32; oracle = "
+                      f"reference op sequence, per-sample grads by vmap)"}
 
 
 def run_job(args, dev, dtype, rank, world, local_b, logical_b, probe):
@@ -224,39 +274,44 @@ def run_job(args, dev, dtype, rank, world, local_b, logical_b, probe):
         step(i)
     torch.cuda.synchronize()
     graphs = g_apply = None
-    if not args.eager and (world == 1 or args.graph_multi):
-        # the launch-bound step (about 60 short kernels) is captured once per input set into a HIP
-        # graph; replays draw fresh noise because the RNG counters live in device memory
+    if not args.eager:
+        # the launch-bound step (about 40 short kernels) is captured once per input set into a HIP
+        # graph; replays draw fresh noise because the RNG counters live in device memory.
         # With several ranks the collective stays OUT of the graphs: one graph per input set for
         # the work before it, one for the update after it, and a plain RCCL all-reduce between.
+        ok = 1
         try:
             graphs, pool = [], None
+            # thread-local capture mode: the process group's watchdog thread may query events
+            # while this thread captures
+            mode = "thread_local" if world > 1 else "global"
             for i in range(len(sets)):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
                     if world == 1:
                         step(i)
                     else:
                         step.local(i)
                 pool = g.pool()
                 graphs.append(g)
-            g_apply = None
             if world > 1:
                 g_apply = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_apply, pool=pool):
+                with torch.cuda.graph(g_apply, pool=pool, capture_error_mode=mode):
                     step.apply()
-            for g in graphs:
-                g.replay()
-                if g_apply is not None:
-                    step.reduce()
-                    g_apply.replay()
-            torch.cuda.synchronize()
         except Exception as exc:  # capture is an optimisation of the launch path only
-            if rank == 0:
-                print(f"[bench] HIP graph capture unavailable ({type(exc).__name__}: {exc}); "
-                      "timing eager launches", file=sys.stderr)
-            graphs = g_apply = None
+            print(f"[bench] rank {rank}: HIP graph capture unavailable ({type(exc).__name__}: {exc}); "
+                  "timing eager launches", file=sys.stderr)
+            ok = 0
             torch.cuda.synchronize()
+        if world > 1:
+            # every rank must take the same path: a rank that fell back to eager launches while the
+            # others replay graphs would still match their collectives one for one, but agreeing
+            # first keeps the run uniform and the reported launch mode true for all ranks
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            graphs = g_apply = None
 
     def run(i):
         if graphs is None:
@@ -267,7 +322,7 @@ def run_job(args, dev, dtype, rank, world, local_b, logical_b, probe):
                 step.reduce()
                 g_apply.replay()
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, len(sets) if graphs is not None else 0)):
         run(i)
     vdist.barrier()
     torch.cuda.synchronize()
@@ -283,8 +338,8 @@ def run_job(args, dev, dtype, rank, world, local_b, logical_b, probe):
     if probe is not None:
         probe.enabled = False
         if graphs is not None:
-            # stream events cannot be read back from inside a replayed graph, so the prune+mix
-            # kernel is timed over the same number of eagerly launched steps right afterwards
+            # event records are refused inside a captured graph on ROCm, so the probed kernels
+            # are timed over the same number of eagerly launched steps right afterwards
             probe.enabled = True
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -319,12 +374,12 @@ def main():
         lo, hi = vdist.shard_range(args.batch, rank, world)
         local_b, logical_b = hi - lo, args.batch
 
-    probe = Probe("gather_mix_pool_multi")
+    probe = Probe("gather_mix_pool_multi", "clipped_sum_linear:")
     ops.PROBE = probe
     dt, launch, eager_ms = run_job(args, dev, dtype, rank, world, local_b, logical_b, probe)
     ops.PROBE = None
     other = None
-    if world > 1:  # the other reading of configs[2]: same logical batch 1024, sharded
+    if world > 1:  # the other scaling mode over the same ranks
         if args.scaling == "weak":
             lo, hi = vdist.shard_range(args.batch, rank, world)
             o_local, o_logical, o_name = hi - lo, args.batch, "strong_scaling_1024"
@@ -342,8 +397,9 @@ def main():
         # every token row read once, the keep indices read, one pooled row written per modality
         Kt = ops.keep_count(N_TXT, 1 - KEEP)
         alg_bytes = local_b * ((N_VIS * D * s + K * 8 + D * s) + (N_TXT * D * s + Kt * 8 + D * s))
-        k_ms = probe.mean_ms()
+        k_ms = probe.mean_ms("gather_mix_pool_multi")
         achieved = alg_bytes / k_ms / 1e6 if k_ms > 0 else 0.0
+        copy_gbs = copy_rate_gbs(dev)
         traffic = None
         try:  # HBM bytes per launch from the PMC passes kept under profiles/ (same shape only)
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
@@ -352,6 +408,18 @@ def main():
                 traffic = pmc["kernels"]["gather_mix_pool_multi_kernel<true, true, 32>"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
+        timing = ("stream events around the launch in eagerly launched steps right after the timed region "
+                  "(the timed region replays HIP graphs)") if launch == "hipgraph" else \
+                 "stream events around the launch inside the timed region"
+        mfma = []
+        for name in sorted(probe.pairs):
+            if not name.startswith("clipped_sum_linear:"):
+                continue
+            out_f, in_f = (int(v) for v in name.split(":")[1].split("x"))
+            ms = probe.mean_ms(name)
+            tf = 2.0 * local_b * out_f * in_f / ms / 1e9 if ms > 0 else 0.0
+            mfma.append({"kernel": f"clipped_sum_linear {out_f}x{in_f} over batch {local_b}", "ms": round(ms, 5),
+                         "tflops": round(tf, 1), "frac_of_2.5PF": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)})
         line = {
             "metric": "DP-SGD train samples/s (fusion+classifier+DP step, token-level inputs)",
             "value": round(logical_b * args.steps / dt, 1),
@@ -370,7 +438,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "gather_mix_pool_multi_kernel (prune+mix, vision + text tokens)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel_ms": round(k_ms, 5), "algorithmic_bytes": alg_bytes},
+                         "kernel_ms": round(k_ms, 5), "algorithmic_bytes": alg_bytes,
+                         "kernel_timing": timing, "copy_rate_same_run_GBs": round(copy_gbs, 1),
+                         "frac_of_copy_rate": round(achieved / copy_gbs, 4) if copy_gbs > 0 else None},
+            "mfma": mfma,
         }
         if other is not None:
             line[other[0]] = other[1]

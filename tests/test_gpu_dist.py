@@ -46,6 +46,38 @@ def _step(dev, x, y, sigma, expected, steps=2):
     return torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu(), first_grad
 
 
+def _graph_step(dev, x, y, expected):
+    """Step 1 eagerly, step 2 as: replayed HIP graph (forward, backward, per-rank DP work) -> eager
+    all-reduce -> replayed HIP graph (update) -- the launch shape bench.py uses with several ranks."""
+    from vqa_amd import dp
+    m = _model(dev)
+    gsm = dp.GradSampleModule(m)
+    opt = dp.DPOptimizer(torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=0.01), gsm,
+                         noise_multiplier=0.0, max_grad_norm=1.0, expected_batch_size=expected, seed=7)
+
+    def local():
+        opt.zero_grad()
+        nn.CrossEntropyLoss()(gsm(x), y).backward()
+        opt.local_step()
+
+    local()
+    opt.reduce_step()
+    opt.apply_step()
+    torch.cuda.synchronize()
+    g_local, g_apply = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_local, capture_error_mode="thread_local"):
+        local()
+    with torch.cuda.graph(g_apply, pool=g_local.pool(), capture_error_mode="thread_local"):
+        opt.apply_step()
+    g_local.replay()
+    # two processes time-share this one GPU: drain the launch stream before the collective
+    torch.cuda.current_stream().synchronize()
+    opt.reduce_step()
+    g_apply.replay()
+    torch.cuda.synchronize()
+    return torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
+
+
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world), VQAF_DIST_BACKEND="gloo", VQAF_SINGLE_DEVICE="1")
@@ -57,7 +89,9 @@ def _worker(rank, world, port, out_dir):
     lo, hi = vdist.shard_range(B, rank, world)
     quiet, quiet_grad = _step(dev, x[lo:hi], y[lo:hi], 0.0, B)
     noisy, _ = _step(dev, x[lo:hi], y[lo:hi], 1.0, B)
-    torch.save({"quiet": quiet, "noisy": noisy, "quiet_grad": quiet_grad}, os.path.join(out_dir, f"r{rank}.pt"))
+    graphed = _graph_step(dev, x[lo:hi], y[lo:hi], B)
+    torch.save({"quiet": quiet, "noisy": noisy, "quiet_grad": quiet_grad, "graphed": graphed},
+               os.path.join(out_dir, f"r{rank}.pt"))
     vdist.barrier()
     torch.distributed.destroy_process_group()
 
@@ -80,5 +114,10 @@ def test_two_ranks_share_one_gpu_over_gloo(tmp_path):
     # Adam divides by sqrt(v): where a gradient is ~0 the last bits of the sum order decide the
     # update's sign, so parameters agree to a fraction of one lr-sized step, not to f32 rounding
     np.testing.assert_allclose(r0["quiet"].numpy(), single.numpy(), rtol=1e-3, atol=2e-4)
+    # graph replay around the eager collective: same replicas on both ranks, same update as the
+    # eagerly launched step (the few f32 atomics of the affine sums may reorder: last bits only)
+    assert torch.equal(r0["graphed"], r1["graphed"])
+    np.testing.assert_allclose(r0["graphed"].numpy(), r0["quiet"].numpy(), rtol=1e-3, atol=2e-4)
+    assert float((r0["graphed"] - r0["quiet"]).abs().max()) < 2e-4
     # noise on: the parameters moved away from the noise-free ones by a noise-sized amount
     assert float((r0["noisy"] - r0["quiet"]).abs().max()) > 1e-4

@@ -488,10 +488,13 @@ class DPOptimizer:
             if t.kind == "linear":
                 sw = self._slice(S, m.weight)
                 sb = self._slice(S, m.bias) if m.bias is not None else None
+                probe = f"clipped_sum_linear:{g.shape[1]}x{a.shape[1]}"
+                ops._probe(probe, "begin")
                 check(lib.vqaf_clipped_sum_linear(ptr(a), ptr(g), None if prescaled else ptr(coef), B,
                                                   a.shape[1], g.shape[1],
                                                   dtype_code(g), 0, ptr(sw), ptr(sb), st),
                       "vqaf_clipped_sum_linear")
+                ops._probe(probe, "end")
             else:
                 check(lib.vqaf_clipped_sum_affine(ptr(a), ptr(g), None if prescaled else ptr(coef), B, g.shape[1],
                                                   dtype_code(g), 0, ptr(self._slice(S, m.weight)),
