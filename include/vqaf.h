@@ -265,6 +265,39 @@ int vqaf_gather_mix_pool_bwd_multi(const void* grad_out, int ld_out, int g_dtype
                                    const vqaf_pool_bwd_mod* mods_host, int n_mod, int B, int D,
                                    int dtype, vqaf_stream_t stream);
 
+/* The whole pruning branch of a modality -- vqaf_head_scores, vqaf_select and
+ * vqaf_gather_mix_pool -- in ONE launch, one workgroup per sample (utils/fusion.py:234-240 with
+ * :253; :243-249 with :254; :159-170).  The second pass over a sample's tokens follows the first
+ * within microseconds, so it is served from cache and HBM sees each token once.
+ * Same keep indices as vqaf_select (same ranking code, same draws for the same rng state and salt);
+ * the pooled features equal vqaf_gather_mix_pool's up to f32 summation order (noise is summed per
+ * keep slot after the rows instead of row by row).  Per modality: seq (B,N,D) bf16, u (B,H,D) f32
+ * from vqaf_fold_query, idx_out (B,K) int64 receives the keep indices, w_out (B,N) f32 the
+ * attention weights (may be NULL); the other fields as in vqaf_select_desc / vqaf_pool_mod.
+ * `sel_rng_state` serves adv_mode 2 of every modality (salted), as in vqaf_select_multi.
+ * Limits: dtype VQAF_BF16, H <= 8, D in {64,128,256,512,1024}, N <= 4096 and about 64 KiB of LDS
+ * per sample (N*H*4 + 8*nextpow2(N) + 12*N + 32*(D+8) bytes); other shapes return VQAF_E_SHAPE /
+ * VQAF_E_DTYPE and the caller uses the separate entry points. */
+typedef struct vqaf_fused_mod {
+  const void* seq;
+  const float* u;
+  const int64_t* pos;
+  const int64_t* src;
+  const float* noise;
+  const uint64_t* noise_rng_state;
+  int64_t* idx_out;
+  float* w_out;
+  uint64_t salt;
+  float alpha, noise_scale;
+  int noise_kind, N, K, adv_mode, k_adv, col0;
+  int noise_counter_offset; /* added to the noise stream's counter: 1 when the selection draws from the
+                               same rng state and the caller advances it once for them (what the
+                               separate launches see: select, advance, pool), else 0 */
+} vqaf_fused_mod;
+int vqaf_fused_prune_pool_multi(const vqaf_fused_mod* mods_host, int n_mod, int B, int D, int H, int dtype,
+                                const uint64_t* sel_rng_state, void* out, int ld_out, int out_dtype,
+                                vqaf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Dense single-query cross-attention (non-pruning branch): the attention OUTPUT of
  * nn.MultiheadAttention(query=q[:,None], key=seq, value=seq), utils/fusion.py:257-268 and

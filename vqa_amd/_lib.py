@@ -47,6 +47,14 @@ class SelectDesc(ctypes.Structure):
                 ("salt", c_uint64), ("N", c_int), ("K", c_int), ("adv_mode", c_int), ("k_adv", c_int)]
 
 
+class FusedMod(ctypes.Structure):
+    """vqaf_fused_mod of include/vqaf.h."""
+    _fields_ = [("seq", c_void_p), ("u", c_void_p), ("pos", c_void_p), ("src", c_void_p), ("noise", c_void_p),
+                ("noise_rng_state", c_void_p), ("idx_out", c_void_p), ("w_out", c_void_p), ("salt", c_uint64),
+                ("alpha", c_float), ("noise_scale", c_float), ("noise_kind", c_int), ("N", c_int), ("K", c_int),
+                ("adv_mode", c_int), ("k_adv", c_int), ("col0", c_int), ("noise_counter_offset", c_int)]
+
+
 class PoolBwdMod(ctypes.Structure):
     """vqaf_pool_bwd_mod of include/vqaf.h."""
     _fields_ = [("idx", c_void_p), ("grad_seq", c_void_p), ("alpha", c_float), ("N", c_int), ("K", c_int),
@@ -89,6 +97,7 @@ SIGNATURES = {
     "vqaf_token_outer": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "vqaf_gather_mix_pool_multi": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "vqaf_gather_mix_pool_bwd_multi": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "vqaf_fused_prune_pool_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
     "vqaf_gemm_f32": (c_int, [_P, c_int, c_long, c_long, c_long, _P, c_int, c_long, c_long, c_long,
                               _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
                               c_float, c_int, _P]),

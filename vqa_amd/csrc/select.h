@@ -1,0 +1,187 @@
+// Keep-index selection building blocks shared by the selection kernels and the fused
+// score -> select -> pool kernel: order-preserving keys, in-LDS ranking, random k-prefixes of a
+// permutation, and the whole "weights -> ranked keep list -> adversarial swap" sequence on LDS arrays.
+#pragma once
+#include "common.h"
+
+constexpr int TK_MAX_N = 4096;
+constexpr int SEL_MAX_H = 16;
+
+__device__ __forceinline__ unsigned int order_key(float w) {
+  unsigned int u = __float_as_uint(w);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;  // NaN ranks above +inf
+  if (u == 0x80000000u) u = 0u;                             // -0 ties with +0
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Sorts keys[0..NP) descending; NP a power of two; all threads of the block take part.
+__device__ inline void bitonic_sort_desc(unsigned long long* keys, int NP) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int k = 2; k <= NP; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int p = tid; p < (NP >> 1); p += nt) {
+        const int t = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+        const int q = t | j;
+        const unsigned long long a = keys[t], c = keys[q];
+        const bool desc = (t & k) == 0;
+        if (desc ? (a < c) : (a > c)) {
+          keys[t] = c;
+          keys[q] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Ranking by counting: rank_i = #{j : key_j > key_i}.  Keys are distinct, so the ranks are a
+// permutation.  Every thread streams the whole key array from LDS with broadcast 16-byte reads
+// (all lanes read the same address: one LDS cycle for two keys) and needs no barrier, which
+// makes one sample's ranking quicker than the 21-36 barrier-separated steps of the bitonic network
+// for rows of up to 256 weights (measured: N = 30: 4.0 vs 5.2 us, N = 197: 7.3 vs 8.3 us per
+// launch); its N^2 work loses beyond that (N = 577: 24 vs 14 us), where the network is kept.
+constexpr int RANK_COUNT_MAX_N = 256;
+__device__ __forceinline__ int count_greater(const unsigned long long* keys, int NP, unsigned long long ki) {
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  int rank = 0;
+#pragma unroll 8
+  for (int j = 0; j < NP; j += 2) {
+    const u64x2 kk = *reinterpret_cast<const u64x2*>(keys + j);
+    rank += (kk.x > ki) ? 1 : 0;
+    rank += (kk.y > ki) ? 1 : 0;
+  }
+  return rank;
+}
+
+// Random k_adv-prefix of a uniform permutation of [0,M): rank M random 51-bit keys (ties are
+// broken by position, probability ~ M^2 / 2^52) and keep the first k_adv positions.
+__device__ inline void random_prefix(unsigned long long* keys, int M, int NP, unsigned long long seed,
+                                     unsigned long long counter, unsigned long long stream_id) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < NP; i += nt) {
+    unsigned long long key = 0ull;
+    if (i < M) {
+      const Philox4 r = philox4x32_10(seed, stream_id * (unsigned long long)TK_MAX_N + i, counter);
+      const unsigned long long r51 = (((unsigned long long)r.x << 32) | r.y) >> 13;
+      key = (1ull << 63) | (r51 << 12) | (unsigned long long)(TK_MAX_N - 1 - i);  // above padding
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  bitonic_sort_desc(keys, NP);
+}
+
+// Same draw as random_prefix, delivered as positions: out[r] = position with rank r, r < take.
+// Uses counting when M is small (identical result: the ranking of the same keys).
+__device__ inline void random_prefix_positions(unsigned long long* keys, int M, int NP, unsigned long long seed,
+                                               unsigned long long counter, unsigned long long stream_id,
+                                               int take, int* out) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if (M > RANK_COUNT_MAX_N) {
+    random_prefix(keys, M, NP, seed, counter, stream_id);
+    for (int j = tid; j < take; j += nt) out[j] = TK_MAX_N - 1 - (int)(keys[j] & (TK_MAX_N - 1));
+    __syncthreads();
+    return;
+  }
+  for (int i = tid; i < NP; i += nt) {
+    unsigned long long key = 0ull;
+    if (i < M) {
+      const Philox4 r = philox4x32_10(seed, stream_id * (unsigned long long)TK_MAX_N + i, counter);
+      const unsigned long long r51 = (((unsigned long long)r.x << 32) | r.y) >> 13;
+      key = (1ull << 63) | (r51 << 12) | (unsigned long long)(TK_MAX_N - 1 - i);
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (int i = tid; i < M; i += nt) {
+    const int r = count_greater(keys, NP, keys[i]);
+    if (r < take) out[r] = i;
+  }
+  __syncthreads();
+}
+
+// LDS arrays of one sample's selection.
+struct SelectLds {
+  unsigned long long* keys;  // [NP]
+  float* sl;                 // [N*H] head scores (16-byte aligned), unused when the weights are given
+  int* rank;                 // [N]   full ranking; the keep list is rank[0..K) on return
+  int* s_pos;                // [2*k_adv] drawn positions, then drawn sources
+  float* wl;                 // [N]   head-averaged weights
+  float* stat;               // [2*SEL_MAX_H]
+};
+
+// Whole keep-index selection of one sample by one workgroup, on LDS arrays:
+//   (H > 0) softmax per head over sl -> head mean -> wl;   keys -> ranking -> rank[];
+//   bottom list reported (before the swap, as the reference keeps it);
+//   adversarial swap with injected (adv_mode 1) or in-kernel (adv_mode 2) draws.
+// On entry sl (H > 0) or wl (H == 0) is filled and visible to the workgroup; on return rank[0..K)
+// is the keep list and all threads have passed a barrier.  pos_b / src_b / the *_out_b pointers are
+// this sample's rows (already offset by the sample index).
+__device__ inline void select_core(const SelectLds& L, int H, int N, int K, int NP, int adv_mode, int k_adv,
+                                   int NPK, int NPR, const int64_t* pos_b, const int64_t* src_b,
+                                   unsigned long long seed, unsigned long long counter, unsigned long long stream_b,
+                                   float* w_out_b, int64_t* bottom_b, int64_t* pos_out_b, int64_t* src_out_b) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  const int R = N - K;
+  if (H > 0) {
+    for (int h = wave; h < H; h += nw) {  // a wave owns a head: no workgroup barrier inside
+      float m = -INFINITY;
+      for (int n = lane; n < N; n += 64) m = fmaxf(m, L.sl[n * H + h]);
+      m = wave_max(m);
+      float z = 0.f;
+      for (int n = lane; n < N; n += 64) z += expf(L.sl[n * H + h] - m);
+      z = wave_sum(z);
+      if (lane == 0) { L.stat[h] = m; L.stat[SEL_MAX_H + h] = z; }
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += nt) {
+      float a = 0.f;
+      for (int h = 0; h < H; ++h) a += expf(L.sl[n * H + h] - L.stat[h]) / L.stat[SEL_MAX_H + h];
+      L.wl[n] = a / (float)H;
+    }
+    __syncthreads();
+  }
+  if (w_out_b != nullptr)
+    for (int n = tid; n < N; n += nt) w_out_b[n] = L.wl[n];
+  for (int i = tid; i < NP; i += nt)
+    L.keys[i] = (i < N) ? (((unsigned long long)order_key(L.wl[i]) << 32) |
+                           (unsigned long long)(0xffffffffu - (unsigned int)i))
+                        : 0ull;
+  __syncthreads();
+  if (N <= RANK_COUNT_MAX_N) {
+    for (int i = tid; i < N; i += nt) L.rank[count_greater(L.keys, NP, L.keys[i])] = i;
+  } else {
+    bitonic_sort_desc(L.keys, NP);
+    for (int r = tid; r < N; r += nt) L.rank[r] = (int)(0xffffffffu - (unsigned int)L.keys[r]);
+  }
+  __syncthreads();
+  if (bottom_b != nullptr)
+    for (int i = tid; i < R; i += nt) bottom_b[i] = (int64_t)L.rank[N - 1 - i];
+
+  if (adv_mode == 1) {
+    for (int j = tid; j < k_adv; j += nt) {
+      const int64_t p = pos_b[j], q = src_b[j];
+      if (p >= 0 && p < K && q >= 0 && q < R) L.rank[p] = L.rank[N - 1 - (int)q];
+    }
+    __syncthreads();
+  } else if (adv_mode == 2) {
+    int* s_src = L.s_pos + k_adv;
+    random_prefix_positions(L.keys, K, NPK, seed, counter, 2ull * stream_b, k_adv, L.s_pos);
+    random_prefix_positions(L.keys, R, NPR, seed, counter, 2ull * stream_b + 1ull, k_adv, s_src);
+    for (int j = tid; j < k_adv; j += nt) {
+      const int p = L.s_pos[j];
+      const int q = s_src[j];
+      L.rank[p] = L.rank[N - 1 - q];  // positions distinct, sources from the untouched tail: no hazard
+      if (pos_out_b != nullptr) pos_out_b[j] = p;
+      if (src_out_b != nullptr) src_out_b[j] = q;
+    }
+    __syncthreads();
+  }
+}
+
+inline int sel_next_pow2(int n) {
+  int p = 64;
+  while (p < n) p <<= 1;
+  return p;
+}

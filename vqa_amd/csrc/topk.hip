@@ -6,57 +6,9 @@
 // so keys are distinct and a descending sort yields (weight desc, index asc); rows are padded
 // to a power of two with key 0, which sorts below every real key.  The sorted prefix is the
 // keep list, the reversed tail the "bottom" list, so the two always partition [0,N).
-#include "common.h"
+#include "select.h"
 
 namespace {
-
-constexpr int TK_MAX_N = 4096;
-
-__device__ __forceinline__ unsigned int order_key(float w) {
-  unsigned int u = __float_as_uint(w);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;  // NaN ranks above +inf
-  if (u == 0x80000000u) u = 0u;                             // -0 ties with +0
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-// Sorts keys[0..NP) descending; NP a power of two; all threads of the block take part.
-__device__ void bitonic_sort_desc(unsigned long long* keys, int NP) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int k = 2; k <= NP; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int p = tid; p < (NP >> 1); p += nt) {
-        const int t = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-        const int q = t | j;
-        const unsigned long long a = keys[t], c = keys[q];
-        const bool desc = (t & k) == 0;
-        if (desc ? (a < c) : (a > c)) {
-          keys[t] = c;
-          keys[q] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// Ranking by counting: rank_i = #{j : key_j > key_i}.  Keys are distinct, so the ranks are a
-// permutation.  Every thread streams the whole key array from LDS with broadcast 16-byte reads
-// (all lanes read the same address: one LDS cycle for two keys) and needs no barrier, which
-// makes one sample's ranking quicker than the 21-36 barrier-separated steps of the bitonic network
-// for rows of up to 256 weights (measured: N = 30: 4.0 vs 5.2 us, N = 197: 7.3 vs 8.3 us per
-// launch); its N^2 work loses beyond that (N = 577: 24 vs 14 us), where the network is kept.
-constexpr int RANK_COUNT_MAX_N = 256;
-__device__ __forceinline__ int count_greater(const unsigned long long* keys, int NP, unsigned long long ki) {
-  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-  int rank = 0;
-#pragma unroll 8
-  for (int j = 0; j < NP; j += 2) {
-    const u64x2 kk = *reinterpret_cast<const u64x2*>(keys + j);
-    rank += (kk.x > ki) ? 1 : 0;
-    rank += (kk.y > ki) ? 1 : 0;
-  }
-  return rank;
-}
 
 __global__ void topk_kernel(const float* __restrict__ w, int N, int K, int NP,
                             int64_t* __restrict__ top, int64_t* __restrict__ bottom) {
@@ -95,53 +47,6 @@ __global__ void adv_swap_kernel(int64_t* __restrict__ top, const int64_t* __rest
   }
 }
 
-// Random k_adv-prefix of a uniform permutation of [0,M): rank M random 51-bit keys (ties are
-// broken by position, probability ~ M^2 / 2^52) and keep the first k_adv positions.
-__device__ void random_prefix(unsigned long long* keys, int M, int NP, unsigned long long seed,
-                              unsigned long long counter, unsigned long long stream_id) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int i = tid; i < NP; i += nt) {
-    unsigned long long key = 0ull;
-    if (i < M) {
-      const Philox4 r = philox4x32_10(seed, stream_id * (unsigned long long)TK_MAX_N + i, counter);
-      const unsigned long long r51 = (((unsigned long long)r.x << 32) | r.y) >> 13;
-      key = (1ull << 63) | (r51 << 12) | (unsigned long long)(TK_MAX_N - 1 - i);  // above padding
-    }
-    keys[i] = key;
-  }
-  __syncthreads();
-  bitonic_sort_desc(keys, NP);
-}
-
-// Same draw as random_prefix, delivered as positions: out[r] = position with rank r, r < take.
-// Uses counting when M is small (identical result: the ranking of the same keys).
-__device__ void random_prefix_positions(unsigned long long* keys, int M, int NP, unsigned long long seed,
-                                        unsigned long long counter, unsigned long long stream_id,
-                                        int take, int* out) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  if (M > RANK_COUNT_MAX_N) {
-    random_prefix(keys, M, NP, seed, counter, stream_id);
-    for (int j = tid; j < take; j += nt) out[j] = TK_MAX_N - 1 - (int)(keys[j] & (TK_MAX_N - 1));
-    __syncthreads();
-    return;
-  }
-  for (int i = tid; i < NP; i += nt) {
-    unsigned long long key = 0ull;
-    if (i < M) {
-      const Philox4 r = philox4x32_10(seed, stream_id * (unsigned long long)TK_MAX_N + i, counter);
-      const unsigned long long r51 = (((unsigned long long)r.x << 32) | r.y) >> 13;
-      key = (1ull << 63) | (r51 << 12) | (unsigned long long)(TK_MAX_N - 1 - i);
-    }
-    keys[i] = key;
-  }
-  __syncthreads();
-  for (int i = tid; i < M; i += nt) {
-    const int r = count_greater(keys, NP, keys[i]);
-    if (r < take) out[r] = i;
-  }
-  __syncthreads();
-}
-
 __global__ void adv_swap_random_kernel(int64_t* __restrict__ top, const int64_t* __restrict__ bottom,
                                        int K, int R, int k_adv, int NPK, int NPR,
                                        const uint64_t* __restrict__ rng_state,
@@ -167,7 +72,6 @@ __global__ void adv_swap_random_kernel(int64_t* __restrict__ top, const int64_t*
 // per head -> head mean, ranking, keep / bottom lists, adversarial swap with injected or in-kernel
 // draws.  Replaces four launches (weights, top-k, swap, counter bump is still separate) and keeps
 // the weights and both index lists in LDS in between.
-constexpr int SEL_MAX_H = 16;
 constexpr int SEL_MAX_MODS = 4;
 struct SelectMod {
   const float* s;
@@ -188,107 +92,52 @@ struct SelectMods {
 __global__ void select_kernel(SelectMods mods, int H, const uint64_t* __restrict__ rng_state) {
   const SelectMod& M_ = mods.m[blockIdx.y];
   const float* __restrict__ s = M_.s;
-  const float* __restrict__ w_in = M_.w_in;
-  const int64_t* __restrict__ pos = M_.pos;
-  const int64_t* __restrict__ src = M_.src;
-  float* __restrict__ w_out = M_.w_out;
-  int64_t* __restrict__ top = M_.top;
-  int64_t* __restrict__ bottom = M_.bottom;
-  int64_t* __restrict__ pos_out = M_.pos_out;
-  int64_t* __restrict__ src_out = M_.src_out;
-  const unsigned long long salt = M_.salt;
-  const int N = M_.N, K = M_.K, NP = M_.NP, adv_mode = M_.adv_mode, k_adv = M_.k_adv, NPK = M_.NPK,
-            NPR = M_.NPR;
+  const int N = M_.N, K = M_.K, NP = M_.NP, k_adv = M_.k_adv;
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [NP]
-  float* sl = reinterpret_cast<float*>(keys + NP);                           // [N*H] head scores (16-B aligned)
+  __shared__ float stat[2 * SEL_MAX_H];
+  SelectLds L;
+  L.keys = keys;
+  L.sl = reinterpret_cast<float*>(keys + NP);                           // [N*H] head scores (16-B aligned)
   const int slots = (s != nullptr) ? ((N * H + 3) & ~3) : 0;
-  int* rank = reinterpret_cast<int*>(sl + slots);                            // [N] full ranking
-  int* s_pos = rank + N;                                                     // [2*k_adv]: positions, sources
-  float* wl = reinterpret_cast<float*>(s_pos + (k_adv > 0 ? 2 * k_adv : 1)); // [N]
-  __shared__ float stat[2][SEL_MAX_H];
+  L.rank = reinterpret_cast<int*>(L.sl + slots);                        // [N] full ranking
+  L.s_pos = L.rank + N;                                                 // [2*k_adv]: positions, sources
+  L.wl = reinterpret_cast<float*>(L.s_pos + (k_adv > 0 ? 2 * k_adv : 1)); // [N]
+  L.stat = stat;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   const int R = N - K;
-
   if (s != nullptr) {
     // one coalesced sweep brings the sample's N x H scores into LDS; every later pass reads LDS
     const float* sb = s + (size_t)b * N * H;
     if (((N * H) & 3) == 0) {  // rows of H floats: 16-byte loads whenever N*H is a multiple of 4
       const f32x4* sb4 = reinterpret_cast<const f32x4*>(sb);
-      f32x4* sl4 = reinterpret_cast<f32x4*>(sl);
+      f32x4* sl4 = reinterpret_cast<f32x4*>(L.sl);
       for (int i = tid; i < (N * H) >> 2; i += nt) sl4[i] = sb4[i];
     } else {
-      for (int i = tid; i < N * H; i += nt) sl[i] = sb[i];
-    }
-    __syncthreads();
-    for (int h = wave; h < H; h += nw) {  // a wave owns a head: no workgroup barrier inside
-      float m = -INFINITY;
-      for (int n = lane; n < N; n += 64) m = fmaxf(m, sl[n * H + h]);
-      m = wave_max(m);
-      float z = 0.f;
-      for (int n = lane; n < N; n += 64) z += expf(sl[n * H + h] - m);
-      z = wave_sum(z);
-      if (lane == 0) { stat[0][h] = m; stat[1][h] = z; }
-    }
-    __syncthreads();
-    for (int n = tid; n < N; n += nt) {
-      float a = 0.f;
-      for (int h = 0; h < H; ++h) a += expf(sl[n * H + h] - stat[0][h]) / stat[1][h];
-      wl[n] = a / (float)H;
+      for (int i = tid; i < N * H; i += nt) L.sl[i] = sb[i];
     }
   } else {
-    for (int n = tid; n < N; n += nt) wl[n] = w_in[(size_t)b * N + n];
+    for (int n = tid; n < N; n += nt) L.wl[n] = M_.w_in[(size_t)b * N + n];
   }
   __syncthreads();
-  if (w_out != nullptr)
-    for (int n = tid; n < N; n += nt) w_out[(size_t)b * N + n] = wl[n];
-  for (int i = tid; i < NP; i += nt)
-    keys[i] = (i < N) ? (((unsigned long long)order_key(wl[i]) << 32) |
-                         (unsigned long long)(0xffffffffu - (unsigned int)i))
-                      : 0ull;
-  __syncthreads();
-  if (N <= RANK_COUNT_MAX_N) {
-    for (int i = tid; i < N; i += nt) rank[count_greater(keys, NP, keys[i])] = i;
-  } else {
-    bitonic_sort_desc(keys, NP);
-    for (int r = tid; r < N; r += nt) rank[r] = (int)(0xffffffffu - (unsigned int)keys[r]);
+  unsigned long long seed = 0, counter = 0;
+  if (M_.adv_mode == 2) {
+    seed = rng_state[0] + M_.salt;
+    counter = rng_state[1];
   }
-  __syncthreads();
-  if (bottom != nullptr)  // the bottom list is reported before the swap, as the reference keeps it
-    for (int i = tid; i < R; i += nt) bottom[(size_t)b * R + i] = (int64_t)rank[N - 1 - i];
-
-  if (adv_mode == 1) {
-    for (int j = tid; j < k_adv; j += nt) {
-      const int64_t p = pos[(size_t)b * k_adv + j], q = src[(size_t)b * k_adv + j];
-      if (p >= 0 && p < K && q >= 0 && q < R) rank[p] = rank[N - 1 - (int)q];
-    }
-    __syncthreads();
-  } else if (adv_mode == 2) {
-    const unsigned long long seed = rng_state[0], counter = rng_state[1];
-    int* s_src = s_pos + k_adv;
-    random_prefix_positions(keys, K, NPK, seed + salt, counter, 2ull * b, k_adv, s_pos);
-    random_prefix_positions(keys, R, NPR, seed + salt, counter, 2ull * b + 1ull, k_adv, s_src);
-    for (int j = tid; j < k_adv; j += nt) {
-      const int p = s_pos[j];
-      const int q = s_src[j];
-      rank[p] = rank[N - 1 - q];  // positions distinct, sources from the untouched tail: no hazard
-      if (pos_out != nullptr) pos_out[(size_t)b * k_adv + j] = p;
-      if (src_out != nullptr) src_out[(size_t)b * k_adv + j] = q;
-    }
-    __syncthreads();
-  }
-  for (int j = tid; j < K; j += nt) top[(size_t)b * K + j] = (int64_t)rank[j];
+  select_core(L, s != nullptr ? H : 0, N, K, NP, M_.adv_mode, k_adv, M_.NPK, M_.NPR,
+              M_.pos ? M_.pos + (size_t)b * k_adv : nullptr, M_.src ? M_.src + (size_t)b * k_adv : nullptr,
+              seed, counter, (unsigned long long)b,
+              M_.w_out ? M_.w_out + (size_t)b * N : nullptr, M_.bottom ? M_.bottom + (size_t)b * R : nullptr,
+              M_.pos_out ? M_.pos_out + (size_t)b * k_adv : nullptr,
+              M_.src_out ? M_.src_out + (size_t)b * k_adv : nullptr);
+  for (int j = tid; j < K; j += nt) M_.top[(size_t)b * K + j] = (int64_t)L.rank[j];
 }
 
 __global__ void rng_advance_kernel(uint64_t* state, uint64_t delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += delta;
 }
 
-inline int next_pow2(int n) {
-  int p = 64;
-  while (p < n) p <<= 1;
-  return p;
-}
+inline int next_pow2(int n) { return sel_next_pow2(n); }
 inline int sort_threads(int NP) {
   int t = NP / 2;
   if (t < 64) t = 64;

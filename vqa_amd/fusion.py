@@ -145,6 +145,7 @@ class Attention(nn.Module):
         self.output_dim = embed_dim * 2
         self.use_pruning = use_pruning
         self.fuse_pool = True  # skip materialising the pruned tokens (same result)
+        self.fuse_select = True  # scoring + selection + pooling of a sample in one workgroup (bf16 tokens)
         if use_pruning:
             # utils/fusion.py:141-146 passes no noise arguments, so the class defaults apply
             # (noise_injection=True, noise_scale=0.01, gaussian).
@@ -154,7 +155,24 @@ class Attention(nn.Module):
     def forward(self, v_seq, v_global, q_seq, q_global, **inject):
         ops.require_gpu(v_seq)  # no CPU fallback: fail before anything else is touched
         if self.use_pruning:
-            if self.fuse_pool:
+            spec = None
+            if self.fuse_pool and self.fuse_select:
+                k, k_adv = self.pruning.plan(v_seq.shape[1])
+                noise_t, noise_type = self.pruning._noise_args(inject.get("noise"))
+                spec = dict(q=q_global, seq=v_seq, in_proj_weight=self.attention.in_proj_weight,
+                            in_proj_bias=self.attention.in_proj_bias, num_heads=self.attention.num_heads, k=k,
+                            k_adv=k_adv, pos=inject.get("replace_positions"), src=inject.get("random_bottom"), salt=0,
+                            alpha=float(self.pruning.mixup_alpha), noise=noise_t, noise_type=noise_type,
+                            noise_scale=float(self.pruning.noise_scale), noise_rng=self.pruning.rng)
+                if not ops.fused_prune_pool_supported([spec]):
+                    spec = None
+            if spec is not None:
+                rng = self.pruning.rng or ops.default_rng(v_seq.device)
+                attended_v, (idx,), drew = ops.fused_prune_pool([spec], v_seq.dtype, rng)
+                if drew:
+                    rng.advance()
+                self.pruning.last_indices = idx
+            elif self.fuse_pool:
                 hs = _head_scores(self.attention, q_global, v_seq)
                 attended_v = ops.pruned_pool([self.pruning.pool_spec(v_seq, None, head_scores=hs, **inject)],
                                              v_seq.dtype)
@@ -179,6 +197,7 @@ class CoAttention(nn.Module):
         self.output_dim = embed_dim * 2
         self.use_pruning = use_pruning
         self.fuse_pool = True
+        self.fuse_select = True  # scoring + selection + pooling of a sample in one workgroup (bf16 tokens)
         if use_pruning:
             self.v_pruning = PrivacyAwareTokenPruning(
                 prune_ratio=prune_ratio, mixup_alpha=mixup_alpha, adversarial_mix=adversarial_mix,
@@ -215,6 +234,19 @@ class CoAttention(nn.Module):
                                           k_adv=k_adv, pos=inj.get("replace_positions"),
                                           src=inj.get("random_bottom"), salt=salt))
                     rng = self.v_pruning.rng or ops.default_rng(v_seq.device)
+                    if self.fuse_select and ops.fused_prune_pool_supported(specs):
+                        # one launch scores, selects and pools both modalities (the tokens of a
+                        # sample are read from HBM once)
+                        v_noise, v_ntype = self.v_pruning._noise_args(v_inject.get("noise"))
+                        specs[0].update(alpha=float(self.v_pruning.mixup_alpha), noise=v_noise, noise_type=v_ntype,
+                                        noise_scale=float(self.v_pruning.noise_scale), noise_rng=self.v_pruning.rng)
+                        specs[1].update(alpha=float(self.q_pruning.mixup_alpha), noise=None, noise_type=None,
+                                        noise_scale=0.0, noise_rng=self.q_pruning.rng)
+                        fused, (v_idx, q_idx), drew = ops.fused_prune_pool(specs, v_seq.dtype, rng)
+                        if drew:
+                            rng.advance()
+                        self.v_pruning.last_indices, self.q_pruning.last_indices = v_idx, q_idx
+                        return fused
                     (v_idx, q_idx), drew = ops.score_select_multi(specs, rng)
                     if drew:
                         rng.advance()

@@ -431,6 +431,139 @@ class _PrunedPool(torch.autograd.Function):
         return tuple(grads)
 
 
+FUSED_WIDTHS = (64, 128, 256, 512, 1024)
+
+
+def fused_prune_pool_supported(specs) -> bool:
+    """True when vqaf_fused_prune_pool_multi covers these modalities (bf16 tokens of one width and
+    batch, at most 8 heads, per-sample state within 64 KiB of LDS)."""
+    s0 = specs[0]["seq"]
+    B, _, D = s0.shape
+    H = specs[0]["num_heads"]
+    if not (1 <= len(specs) <= 4) or s0.dtype != torch.bfloat16 or D not in FUSED_WIDTHS or H > 8:
+        return False
+    for sp in specs:
+        seq = sp["seq"]
+        if seq.dtype != torch.bfloat16 or seq.shape[0] != B or seq.shape[2] != D or sp["num_heads"] != H:
+            return False
+        N = seq.shape[1]
+        NP = 64
+        while NP < N:
+            NP *= 2
+        lds = max(32 * (D + 8), 16384) + 8 * NP + N * H * 4 + 12 * N + 8 * max(1, sp.get("k_adv", 0)) + 512
+        if N > 4096 or lds > 64 * 1024:
+            return False
+    return True
+
+
+class _FusedPrunePool(torch.autograd.Function):
+    """Scoring + selection + pooled prune/mix of several modalities: two launches for the query
+    folds, ONE for everything that touches tokens.  Returns (fused (B, n*D), idx_0, idx_1, ...).
+    The backward is the pooled prune/mix backward (scores and indices carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, n_mod, out_dtype, rng_state, *flat):
+        import ctypes
+        per = 14
+        mods = [flat[i * per:(i + 1) * per] for i in range(n_mod)]
+        seq0 = mods[0][0]
+        B, _, D = seq0.shape
+        dev = seq0.device
+        H = mods[0][4]
+        lib, st = load(), stream_ptr(dev)
+        w_dt = mods[0][2].dtype
+        ld = n_mod * D
+        out = torch.empty(B, ld, dtype=out_dtype, device=dev)
+        folds = (_lib.FoldDesc * n_mod)()
+        fm = (_lib.FusedMod * n_mod)()
+        keep, idxs, metas = [], [], []
+        for i, (seq, q, w, bia, _h, k, k_adv, pos, src, salt, alpha, noise, kind, scale_state) in enumerate(mods):
+            noise_scale, noise_state = scale_state
+            seq_c = seq.contiguous()
+            N = seq_c.shape[1]
+            q_c = q.reshape(B, D).to(seq_c.dtype).contiguous()
+            w_c = w.detach().contiguous()
+            b_c = bia.detach().to(w_c.dtype).contiguous()
+            qp = torch.empty(B, D, dtype=torch.float32, device=dev)
+            u = torch.empty(B, H, D, dtype=torch.float32, device=dev)
+            idx = torch.empty(B, k, dtype=torch.int64, device=dev)
+            mode = 0
+            if k_adv > 0:
+                mode = 1 if pos is not None else 2
+                if mode == 1:
+                    pos, src = pos.to(torch.int64).contiguous(), src.to(torch.int64).contiguous()
+            noise_c = noise.to(torch.float32).contiguous() if noise is not None else None
+            keep.append((seq_c, q_c, w_c, b_c, qp, u, pos, src, noise_c, noise_state))
+            folds[i] = _lib.FoldDesc(ptr(q_c), ptr(w_c), ptr(b_c), ptr(qp), ptr(u))
+            fm[i] = _lib.FusedMod(ptr(seq_c), ptr(u), ptr(pos) if mode == 1 else None, ptr(src) if mode == 1 else None,
+                                  ptr(noise_c), ptr(noise_state), ptr(idx), None, int(salt), float(alpha),
+                                  float(noise_scale), int(kind), N, int(k), mode, int(k_adv), i * D,
+                                  int(rng_state is not None and noise_state is not None
+                                      and noise_state.data_ptr() == rng_state.data_ptr()))
+            idxs.append(idx)
+            metas.append((N, int(k), D, float(alpha), seq.dtype, i * D))
+        check(lib.vqaf_fold_query_multi(ctypes.cast(folds, ctypes.c_void_p), n_mod, B, D, H, dtype_code(seq0),
+                                        _lib.BF16 if w_dt == torch.bfloat16 else _lib.F32, st), "vqaf_fold_query_multi")
+        _probe("fused_prune_pool", "begin")
+        check(lib.vqaf_fused_prune_pool_multi(ctypes.cast(fm, ctypes.c_void_p), n_mod, B, D, H, dtype_code(seq0),
+                                              ptr(rng_state), ptr(out), ld, dtype_code(out), st),
+              "vqaf_fused_prune_pool_multi")
+        _probe("fused_prune_pool", "end")
+        for (_s, _q, _w, _b, _qp, _u, _p, _sr, noise_c, noise_state), m in zip(keep, mods):
+            if noise_state is not None and m[12] != _lib.NOISE_NONE and noise_c is None:
+                check(lib.vqaf_rng_advance(ptr(noise_state), 1, st), "vqaf_rng_advance")
+        ctx.save_for_backward(*idxs)
+        ctx.metas = metas
+        ctx.B, ctx.ld, ctx.n_mod, ctx.per = B, ld, n_mod, per
+        ctx.mark_non_differentiable(*idxs)
+        return (out, *idxs)
+
+    @staticmethod
+    def backward(ctx, grad_out, *_unused):
+        import ctypes
+        g = grad_out.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        lib, st = load(), stream_ptr(g.device)
+        outs = []
+        for i, (N, K, D, alpha, sdt, col0) in enumerate(ctx.metas):
+            need = ctx.needs_input_grad[3 + ctx.per * i]
+            outs.append(torch.empty(ctx.B, N, D, dtype=sdt, device=g.device) if need else None)
+        if any(o is not None for o in outs):
+            arr = (_lib.PoolBwdMod * ctx.n_mod)()
+            for i, (idx_c, (N, K, D, alpha, sdt, col0)) in enumerate(zip(ctx.saved_tensors, ctx.metas)):
+                arr[i] = _lib.PoolBwdMod(ptr(idx_c), ptr(outs[i]), alpha, N, K, col0)
+            check(lib.vqaf_gather_mix_pool_bwd_multi(ptr(g), ctx.ld, dtype_code(g), ctypes.cast(arr, ctypes.c_void_p),
+                                                     ctx.n_mod, ctx.B, ctx.metas[0][2], _lib.BF16, st),
+                  "vqaf_gather_mix_pool_bwd_multi")
+        grads = [None, None, None]
+        for o in outs:
+            grads.extend([o] + [None] * (ctx.per - 1))
+        return tuple(grads)
+
+
+def fused_prune_pool(specs, out_dtype: torch.dtype, rng: Optional["PhiloxState"] = None):
+    """specs: list of dicts(q, seq, in_proj_weight, in_proj_bias, num_heads, k, k_adv, pos, src, salt,
+    alpha, noise, noise_type, noise_scale, noise_rng).  Returns (fused, [keep indices], drew)."""
+    flat, drew = [], False
+    dev = specs[0]["seq"].device
+    for i, sp in enumerate(specs):
+        kind = _noise_kind(sp.get("noise_type")) if sp.get("noise") is None else _lib.NOISE_NONE
+        state = None
+        if kind != _lib.NOISE_NONE:
+            state = (sp.get("noise_rng") or default_rng(dev)).state
+        k_adv = int(sp.get("k_adv", 0))
+        if k_adv > 0 and sp.get("pos") is None:
+            drew = True
+        flat.extend([sp["seq"], sp["q"], sp["in_proj_weight"], sp["in_proj_bias"], sp["num_heads"], sp["k"], k_adv,
+                     sp.get("pos"), sp.get("src"), sp.get("salt", i), sp["alpha"], sp.get("noise"), kind,
+                     (sp.get("noise_scale", 0.0), state)])
+    if drew and rng is None:
+        rng = default_rng(dev)
+    res = _FusedPrunePool.apply(len(specs), out_dtype, rng.state if drew else None, *flat)
+    return res[0], list(res[1:]), drew
+
+
 def pruned_pool(mods, out_dtype: torch.dtype) -> torch.Tensor:
     """mods: list of dicts(seq, idx, alpha, noise, noise_type, noise_scale, rng)."""
     flat = []
