@@ -335,6 +335,25 @@ int vqaf_gemm_f32(const void* A, int a_dtype, long a_sg, long a_sm, long a_sk, c
                   long bias_sg, float* C, long c_sg, long c_sm, int G, int M, int N, int K,
                   float alpha, int beta_one, vqaf_stream_t stream);
 
+/* bf16 GEMM on the matrix cores for the classifier's three uses of a Linear under DP-SGD
+ * (model/model.py:54-63 wrapped at train.py:124-141):
+ *   C[m][n] = sum_k A(m,k) B(k,n) (+ bias[n]),   f32 accumulation,
+ *   A(m,k) = a_kmajor ? A[k*lda + m] : A[m*lda + k],   B(k,n) = b_kmajor ? B[k*ldb + n] : B[n*ldb + k]
+ *   forward  y = x W^T + b : A = x,  B = W (out,in) k-contiguous, bias, C bf16
+ *   dgrad    gx = gy W     : A = gy, B = W (out,in) k-major, C bf16
+ *   clipped sum S = G^T A  : A = G (batch,out) k-major, B = A (batch,in) k-major, C f32, colsum =
+ *                            sum_b G[b][m] (the bias gradient); rows of G already carry the clip factor.
+ * A, B bf16; C f32 or bf16 (c_dtype); bias f32 or bf16 (bias_dtype) or NULL; accumulate != 0 adds
+ * into an f32 C (and colsum).  Few output tiles with an f32 C split the contraction over workgroups
+ * and add partial tiles with f32 atomics (summation order then varies from run to run).
+ * vqaf_gemm_bf16_supported tells whether the layout is covered: row pitches multiples of 8
+ * elements, a k-contiguous operand needs K % 8 == 0, a k-major operand needs its row pitch to
+ * cover the row count rounded up to 8; otherwise VQAF_E_ALIGN (use another GEMM). */
+int vqaf_gemm_bf16_supported(long lda, int a_kmajor, long ldb, int b_kmajor, int M, int N, int K);
+int vqaf_gemm_bf16(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int M, int N,
+                   int K, const void* bias, int bias_dtype, void* C, long ldc, int c_dtype, int accumulate,
+                   float* colsum, vqaf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * DP-SGD step for the classifier.  The reference delegates this to Opacus 1.4.0
  * (GradSampleModule hooks + DPOptimizer.clip_and_accumulate / add_noise / scale_grad),

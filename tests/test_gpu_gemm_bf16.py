@@ -1,0 +1,85 @@
+"""GPU: vqaf_gemm_bf16 (LDS-DMA ring + MFMA) against an f64 contraction of the same bf16 operands,
+for the three operand layouts the classifier uses, benchmark-sized and ragged shapes, row pitches
+larger than the row, bias / accumulate / column-sum epilogues and the split contraction."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from vqa_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _operand(seed, rows, cols, pitch, dev, scale=1.0):
+    """(device view (rows, cols) with row pitch `pitch`, f64 host copy); the padding holds junk."""
+    full = (gi.normal(seed, rows, pitch) * scale).bfloat16()
+    return full.to(dev)[:, :cols], full[:, :cols].double()
+
+
+CASES = [
+    # layout, M, N, K                      (a_kmajor, b_kmajor)
+    ("fwd", 1024, 2048, 1024), ("fwd", 1024, 1024, 2048), ("fwd", 1024, 430, 1024),
+    ("dgrad", 1024, 1024, 2048), ("dgrad", 1024, 2048, 1024),
+    ("wgrad", 2048, 1024, 1024), ("wgrad", 1024, 2048, 1024), ("wgrad", 430, 1024, 1024),
+    # ragged: partial tiles in M and N, k tails, one k-step, more k-steps than ring slots
+    ("fwd", 37, 70, 64), ("fwd", 130, 9, 200), ("fwd", 1, 1, 8), ("fwd", 300, 129, 520),
+    ("dgrad", 70, 100, 72), ("dgrad", 33, 64, 448), ("dgrad", 257, 130, 8),
+    ("wgrad", 100, 70, 37), ("wgrad", 13, 66, 9), ("wgrad", 200, 136, 300), ("wgrad", 64, 64, 1),
+]
+
+
+@pytest.mark.parametrize("layout,M,N,K", CASES)
+def test_gemm_bf16_layouts_and_edges(dev, layout, M, N, K):
+    from vqa_amd import ops
+    up8 = lambda v: (v + 7) // 8 * 8  # noqa: E731
+    if layout == "fwd":      # A (M,K) k-contiguous, B (N,K) k-contiguous
+        A, Ah = _operand(1, M, K, up8(K) + 8, dev)
+        B, Bh = _operand(2, N, K, up8(K), dev)
+        want = Ah @ Bh.t()
+        ak, bk = False, False
+    elif layout == "dgrad":  # A (M,K) k-contiguous, B (K,N) k-major
+        A, Ah = _operand(3, M, K, up8(K), dev)
+        B, Bh = _operand(4, K, N, up8(N) + 16, dev)
+        want = Ah @ Bh
+        ak, bk = False, True
+    else:                    # A (K,M) k-major, B (K,N) k-major
+        A, Ah = _operand(5, K, M, up8(M), dev, scale=0.1)
+        B, Bh = _operand(6, K, N, up8(N), dev)
+        want = Ah.t() @ Bh
+        ak, bk = True, True
+    assert ops.gemm_bf16_supported(A.stride(0), ak, B.stride(0), bk, M, N, K)
+    scale = float(want.abs().max()) + 1e-30
+    # f32 output, plain store
+    C = torch.full((M, N + 3), float("nan"), device=dev)[:, :N]
+    colsum = torch.full((M,), float("nan"), device=dev) if ak else None
+    ops.gemm_bf16(A, ak, B, bk, M, N, K, C, colsum=colsum)
+    np.testing.assert_allclose(C.cpu().numpy(), want.numpy(), rtol=1e-5, atol=3e-6 * scale)
+    if ak:
+        cs = Ah.sum(0)
+        np.testing.assert_allclose(colsum.cpu().numpy(), cs.numpy(), rtol=1e-5, atol=3e-6 * float(cs.abs().max()))
+    # accumulate adds a second product
+    ops.gemm_bf16(A, ak, B, bk, M, N, K, C, accumulate=True, colsum=colsum)
+    np.testing.assert_allclose(C.cpu().numpy(), 2 * want.numpy(), rtol=1e-5, atol=6e-6 * scale)
+    # bf16 output with a bias (what the forward uses); f32 bias and bf16 bias
+    if not ak:
+        bias = gi.normal(7, N)
+        for bt in (bias.to(dev), bias.bfloat16().to(dev)):
+            Cb = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm_bf16(A, ak, B, bk, M, N, K, Cb, bias=bt)
+            wb = want + bt.double().cpu()[None, :]
+            np.testing.assert_allclose(Cb.double().cpu().numpy(), wb.numpy(), rtol=2 ** -8, atol=2 ** -8 * scale)
+
+
+def test_gemm_bf16_rejects_uncovered_layouts(dev):
+    from vqa_amd import ops
+    assert not ops.gemm_bf16_supported(430, True, 1024, True, 430, 1024, 1024)   # row pitch not a multiple of 8
+    assert not ops.gemm_bf16_supported(430, False, 1024, True, 64, 1024, 430)    # k-contiguous operand, K % 8 != 0
+    assert ops.gemm_bf16_supported(432, True, 1024, True, 430, 1024, 1024)       # padded pitch covers the tail

@@ -1,0 +1,501 @@
+// bf16 MFMA GEMM for the classifier under DP-SGD: C (M,N) = op(A) op(B) with f32 accumulation,
+//   forward   y  = x W^T + b        A = x (M,K) k-contiguous,  B = W (N,K) k-contiguous
+//   dgrad     gx = gy W             A = gy (M,K) k-contiguous, B = W (K,N) k-major
+//   wgrad     S  = G^T A            A = G (K,M) k-major,       B = A (K,N) k-major   (clipped sums:
+//             the contraction index is the batch; rows of G are already scaled by the clip factor)
+// These are small GEMMs (about 1024 x 2048 x 1024): a few hundred output tiles and 16-32 k-steps,
+// so what bounds them is the latency of each k-step's operand fetch, not MFMA issue.  Structure:
+//   * tiles of 128 x 64 or 64 x 64 outputs so that every shape gives >= 256 workgroups;
+//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no registers), four
+//     k-steps of 64 deep in a ring: three k-steps are in flight while one is multiplied, waits are
+//     counted (s_waitcnt vmcnt(N)) and there is ONE raw s_barrier per k-step;
+//   * an LDS-DMA writes wave-linear bytes, so the LDS images are unpadded and bank conflicts are
+//     removed by an XOR swizzle applied to the SOURCE address when the tile is fetched and to the
+//     LDS address when fragments are read (k-major images: ds_read_b64_tr_b16, the transposing
+//     read; k-contiguous images: ds_read_b128);
+//   * rows / k-ranges outside the matrix are fetched from a 16-byte block of zeros, so the loop
+//     has no edge cases; out-of-range outputs are masked at the store.
+#include <atomic>
+#include <mutex>
+#include <type_traits>
+
+#include "common.h"
+
+// 16 bytes of zeros in device memory: the source of every out-of-range operand chunk.  As with any
+// file-scope device array, host code must not pass the NAME to a kernel; it asks for the device
+// address once per device and uses that.
+static __device__ __align__(16) unsigned int gb_zero_block[4] = {0u, 0u, 0u, 0u};
+
+namespace {
+
+constexpr int GB_THREADS = 256;
+constexpr int GB_BK = 64;
+constexpr int GB_BN = 64;
+constexpr int GB_STAGES = 4;
+
+typedef short gb_s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { GB_OUT_F32 = 0, GB_OUT_F32_ACC = 1, GB_OUT_F32_ATOMIC = 2, GB_OUT_BF16 = 3 };
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  const void* bias;       // (N) or NULL
+  void* C;
+  float* colsum;          // (M) sum over k of A(m,k), or NULL
+  const unsigned int* zeros;
+  long lda, ldb, ldc;
+  int M, N, K, k_per_split, out_mode, bias_bf16;
+  int tiles_m, tiles_n, reg_m, reg_n;  // output tiles; XCD regions (reg_m * reg_n == 8) or 0
+};
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else static_assert(N == 0, "add the literal");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+  else static_assert(N == 0, "add the literal");
+}
+
+// Swizzle of a k-major image [64 k][W columns] (row pitch 2W bytes, a multiple of 128): the 16-byte
+// chunk c of k-row k is stored at chunk position c ^ kswz(k).  A transposing read touches 4
+// consecutive k-rows x 64 bytes per 32 lanes; the XOR moves those four segments onto disjoint banks.
+template <int W>
+__device__ __forceinline__ int kswz(int k) {
+  if constexpr (W >= 128) return (k & 3) << 2;   // 64-byte steps inside a >= 256-byte row
+  else return ((k >> 1) & 1) << 2;               // 128-byte rows: rows k and k+2 share banks
+}
+// Swizzle of a k-contiguous image [rows][64 k] (128-byte rows): chunk c (8 k values) of row r is
+// stored at chunk position c ^ ((r >> 1) & 7): the 16 rows a ds_read_b128 lane group touches then
+// fall on 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int rswz(int r) { return (r >> 1) & 7; }
+
+template <int MT, bool A_KMAJOR, bool B_KMAJOR, bool COLSUM>
+__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile_m, const int tile_n) {
+  constexpr int BM = 64 * MT;
+  constexpr int A_BYTES = BM * GB_BK * 2;
+  constexpr int B_BYTES = GB_BN * GB_BK * 2;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int NLA = A_BYTES / (GB_THREADS * 16);  // LDS-DMA instructions per thread and k-step, A
+  constexpr int NLB = B_BYTES / (GB_THREADS * 16);
+  constexpr int LPS = NLA + NLB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gb_lds[];
+
+  // Waves 0-3 multiply, waves 4-7 only fetch: an LDS-DMA instruction holds its wave's issue slot for
+  // a long time, so fetch and MFMA streams live in different waves and overlap on the SIMDs.
+  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: LDS-DMA bases stay in SGPRs
+  const bool is_loader = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int tid = threadIdx.x & (GB_THREADS - 1), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = tile_m * BM, n0 = tile_n * GB_BN;
+  const int k_lo = blockIdx.z * g.k_per_split;
+  const int k_hi = min(g.K, k_lo + g.k_per_split);
+  const int T = (k_hi - k_lo + GB_BK - 1) / GB_BK;
+  if (T <= 0) return;
+  const unsigned char* zeros = reinterpret_cast<const unsigned char*>(g.zeros);
+
+  if (is_loader) {
+  // ---- per-thread source descriptors of its chunks (fixed over the k loop) ----
+  // k-major operand: chunk q -> (k row q / CPR, swizzled chunk position q % CPR)
+  // k-contiguous   : chunk q -> (row q / 8, swizzled chunk position q % 8)
+  long a_off[NLA], b_off[NLB];   // element offset of the chunk at k-step 0 (k_lo included)
+  int a_k[NLA], b_k[NLB];        // k (within the k-step) of the chunk's first element
+  bool a_ok[NLA], b_ok[NLB];     // row / column inside the matrix
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) {
+    const int q = j * GB_THREADS + tid;
+    if constexpr (A_KMAJOR) {
+      constexpr int CPR = BM / 8;
+      const int k = q / CPR, c = (q % CPR) ^ kswz<BM>(k);
+      const int m = m0 + c * 8;
+      a_k[j] = k;
+      a_ok[j] = m < g.M;   // chunks never straddle the row end: lda covers M rounded up to 8
+      a_off[j] = (long)(k_lo + k) * g.lda + m;
+    } else {
+      const int r = q / 8, c = (q % 8) ^ rswz(r);
+      a_k[j] = c * 8;
+      a_ok[j] = true;      // rows past M repeat the last row; their outputs are masked
+      a_off[j] = (long)min(m0 + r, g.M - 1) * g.lda + k_lo + c * 8;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    const int q = j * GB_THREADS + tid;
+    if constexpr (B_KMAJOR) {
+      constexpr int CPR = GB_BN / 8;
+      const int k = q / CPR, c = (q % CPR) ^ kswz<GB_BN>(k);
+      const int n = n0 + c * 8;
+      b_k[j] = k;
+      b_ok[j] = n < g.N;
+      b_off[j] = (long)(k_lo + k) * g.ldb + n;
+    } else {
+      const int r = q / 8, c = (q % 8) ^ rswz(r);
+      b_k[j] = c * 8;
+      b_ok[j] = true;
+      b_off[j] = (long)min(n0 + r, g.N - 1) * g.ldb + k_lo + c * 8;
+    }
+  }
+  const long a_step = A_KMAJOR ? (long)GB_BK * g.lda : (long)GB_BK;
+  const long b_step = B_KMAJOR ? (long)GB_BK * g.ldb : (long)GB_BK;
+  const int kspan = k_hi - k_lo;
+
+  // branch-free choice between the chunk's address and the block of zeros
+  auto pick = [&](bool ok, const bf16_t* p) -> const void* {
+    const unsigned long long m = ok ? ~0ull : 0ull;
+    return reinterpret_cast<const void*>((reinterpret_cast<unsigned long long>(p) & m) |
+                                         (reinterpret_cast<unsigned long long>(zeros) & ~m));
+  };
+  auto issue = [&](int t) {
+    unsigned char* st = gb_lds + (t % GB_STAGES) * STAGE_BYTES + wave * 1024;
+    const int kbase = t * GB_BK;
+#pragma unroll
+    for (int j = 0; j < NLA; ++j)
+      glds16(pick(a_ok[j] && (kbase + a_k[j] < kspan), g.A + a_off[j] + (long)t * a_step),
+             st + j * GB_THREADS * 16);
+#pragma unroll
+    for (int j = 0; j < NLB; ++j)
+      glds16(pick(b_ok[j] && (kbase + b_k[j] < kspan), g.B + b_off[j] + (long)t * b_step),
+             st + A_BYTES + j * GB_THREADS * 16);
+  };
+
+    // three k-steps in flight; k-step t has landed when at most min(2, T-1-t) younger k-steps of
+    // this wave are outstanding.  After the barrier every consumer is done with k-step t-1, whose
+    // ring slot the next fetch overwrites.
+#pragma unroll
+    for (int s = 0; s < GB_STAGES - 1; ++s)
+      if (s < T) issue(s);
+    for (int t = 0; t < T; ++t) {
+      const int younger = min(GB_STAGES - 2, T - 1 - t);
+      if (younger >= 2) wait_vmcnt<2 * LPS>();
+      else if (younger == 1) wait_vmcnt<LPS>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (t + GB_STAGES - 1 < T) issue(t + GB_STAGES - 1);
+    }
+    return;
+  }
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  f32x16 csum[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) csum[i][r] = 0.f;
+  gb_bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  // Fragment reads are inline assembly on purpose: for an LDS read it can see, hipcc waits until
+  // EVERY outstanding LDS-DMA has landed (vmcnt(0)), which would drain the ring at each k-step.
+  // The hand-placed vmcnt / barrier above each k-step is what orders these reads.
+  const unsigned lds_base = (unsigned)reinterpret_cast<size_t>(
+      (__attribute__((address_space(3))) unsigned char*)gb_lds);
+  // k-major image of width W: byte address (within the image) of this lane's first transposing
+  // read at k16 step 0; the second read is 4 k-rows further, k16 step ks adds 16 rows.  The swizzle
+  // term depends on (k & 3) or ((k >> 1) & 1) only, so it is the same for every step.
+  auto kmajor_addr = [&](auto wtag, int colbase) -> unsigned {
+    constexpr int W = decltype(wtag)::value;
+    const int i = lane & 15, g16 = lane >> 4;
+    const int krow = 8 * (g16 >> 1) + (i >> 2);
+    const int c0 = (colbase + 16 * (g16 & 1) + 4 * (i & 3)) * 2;  // byte in row; the XOR flips bits >= 6
+    return (unsigned)(krow * (2 * W) + (c0 ^ (kswz<W>(krow) << 4)));
+  };
+  auto read_tr = [&](unsigned addr) -> u32x2 {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+  };
+  auto read_b128 = [&](unsigned addr) -> u32x4 {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+  };
+  typedef std::integral_constant<int, BM> WA;
+  typedef std::integral_constant<int, GB_BN> WB;
+  unsigned a_addr[MT], b_addr;
+  int a_row[MT], b_row;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    a_row[i] = wm * (32 * MT) + i * 32 + (lane & 31);
+    if constexpr (A_KMAJOR) a_addr[i] = kmajor_addr(WA{}, wm * (32 * MT) + i * 32);
+    else a_addr[i] = (unsigned)(a_row[i] * 128);
+  }
+  b_row = wn * 32 + (lane & 31);
+  if constexpr (B_KMAJOR) b_addr = A_BYTES + kmajor_addr(WB{}, wn * 32);
+  else b_addr = (unsigned)(A_BYTES + b_row * 128);
+
+  struct Frags {
+    u32x4 a[MT];
+    u32x4 b;
+  };
+  // issues the LDS reads of k16 step ks of the image at LDS byte address `img`
+  auto load_frags = [&](Frags& f, unsigned img, int ks) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if constexpr (A_KMAJOR) {
+        const unsigned ad = img + a_addr[i] + (unsigned)(ks * 16 * 2 * BM);
+        const u32x2 lo = read_tr(ad), hi = read_tr(ad + 4 * 2 * BM);
+        f.a[i] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      } else {
+        f.a[i] = read_b128(img + a_addr[i] + (unsigned)((((2 * ks + (lane >> 5)) ^ rswz(a_row[i]))) << 4));
+      }
+    }
+    if constexpr (B_KMAJOR) {
+      const unsigned ad = img + b_addr + (unsigned)(ks * 16 * 2 * GB_BN);
+      const u32x2 lo = read_tr(ad), hi = read_tr(ad + 4 * 2 * GB_BN);
+      f.b = u32x4{lo.x, lo.y, hi.x, hi.y};
+    } else {
+      f.b = read_b128(img + b_addr + (unsigned)((((2 * ks + (lane >> 5)) ^ rswz(b_row))) << 4));
+    }
+  };
+  constexpr int READS_PER_KS = (A_KMAJOR ? 2 * MT : MT) + (B_KMAJOR ? 2 : 1);
+  auto as_bf16x8 = [](const u32x4& v) -> gb_bf16x8 {
+    union { u32x4 u; gb_bf16x8 b; } c;
+    c.u = v;
+    return c.b;
+  };
+  auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(f.a[i]), as_bf16x8(f.b), acc[i], 0, 0, 0);
+      if constexpr (COLSUM)
+        csum[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(f.a[i]), ones, csum[i], 0, 0, 0);
+    }
+  };
+
+  for (int t = 0; t < T; ++t) {
+    // the loaders waited for their parts of k-step t before this barrier
+    __builtin_amdgcn_s_barrier();
+    const unsigned img = lds_base + (unsigned)((t % GB_STAGES) * STAGE_BYTES);
+    // the reads of k16 step ks+1 are in flight while step ks multiplies
+    Frags f0, f1;
+    load_frags(f0, img, 0);
+    load_frags(f1, img, 1);
+    wait_lgkmcnt<READS_PER_KS>();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(f0, img, 2);
+    wait_lgkmcnt<READS_PER_KS>();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(f1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(f1, img, 3);
+    wait_lgkmcnt<READS_PER_KS>();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(f0);
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(f1);
+  }
+
+  // ---- epilogue.  C/D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  const int n = n0 + wn * 32 + (lane & 31);
+  float bias_v = 0.f;
+  if (g.bias != nullptr && n < g.N)
+    bias_v = g.bias_bf16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(g.bias)[n])
+                         : reinterpret_cast<const float*>(g.bias)[n];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m < g.M && n < g.N) {
+        const float v = acc[i][r] + bias_v;
+        if (g.out_mode == GB_OUT_BF16) {
+          reinterpret_cast<bf16_t*>(g.C)[(size_t)m * g.ldc + n] = f32_to_bf16(v);
+        } else {
+          float* p = reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n;
+          if (g.out_mode == GB_OUT_F32_ATOMIC) atomicAdd(p, v);
+          else if (g.out_mode == GB_OUT_F32_ACC) *p += v;
+          else *p = v;
+        }
+      }
+      if (COLSUM && wn == 0 && (lane & 31) == 0 && m < g.M) {
+        float* p = g.colsum + m;
+        if (g.out_mode == GB_OUT_F32_ATOMIC) atomicAdd(p, csum[i][r]);
+        else if (g.out_mode == GB_OUT_F32_ACC) *p += csum[i][r];
+        else *p = csum[i][r];
+      }
+    }
+  }
+}
+
+template <int MT, bool A_KMAJOR, bool B_KMAJOR>
+__global__ void __launch_bounds__(2 * GB_THREADS)
+gemm_bf16_kernel(GemmArgs g) {
+  // Workgroup -> output tile.  Workgroups are dealt round-robin over the 8 XCDs, each with its own
+  // L2, so ids with equal (id % 8) share an L2.  When the tile grid splits into 8 equal rectangular
+  // regions, each XCD gets one region: its workgroups then share a few operand panels that fit its
+  // L2, instead of every XCD streaming all of A (speed only; any mapping is correct).
+  int tile_m, tile_n;
+  {
+    const int id = blockIdx.x;
+    if (g.reg_m > 0) {
+      const int xcd = id & 7, slot = id >> 3;
+      const int bm = g.tiles_m / g.reg_m, bn = g.tiles_n / g.reg_n;
+      tile_m = (xcd / g.reg_n) * bm + slot / bn;
+      tile_n = (xcd % g.reg_n) * bn + slot % bn;
+    } else {
+      tile_m = id / g.tiles_n;
+      tile_n = id % g.tiles_n;
+    }
+  }
+  // the column-sum variant of the loop runs only in the workgroups of the first tile column, as a
+  // separate instantiation: a runtime condition around its MFMAs would make the compiler shuttle
+  // the extra accumulators between register files at every k-step of every workgroup
+  if (g.colsum != nullptr && tile_n == 0) gemm_bf16_body<MT, A_KMAJOR, B_KMAJOR, true>(g, tile_m, tile_n);
+  else gemm_bf16_body<MT, A_KMAJOR, B_KMAJOR, false>(g, tile_m, tile_n);
+}
+
+constexpr int GB_MAX_DEVICES = 64;
+std::atomic<const unsigned int*> g_zero_ptr[GB_MAX_DEVICES];
+std::mutex g_zero_mu;
+
+int zero_block_on_current_device(const unsigned int** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GB_MAX_DEVICES) return VQAF_E_LAUNCH;
+  const unsigned int* p = g_zero_ptr[dev].load(std::memory_order_acquire);
+  if (p == nullptr) {
+    std::lock_guard<std::mutex> lock(g_zero_mu);
+    p = g_zero_ptr[dev].load(std::memory_order_relaxed);
+    if (p == nullptr) {
+      void* addr = nullptr;
+      if (hipGetSymbolAddress(&addr, HIP_SYMBOL(gb_zero_block)) != hipSuccess || addr == nullptr) {
+        (void)hipGetLastError();
+        return VQAF_E_LAUNCH;
+      }
+      p = reinterpret_cast<const unsigned int*>(addr);
+      g_zero_ptr[dev].store(p, std::memory_order_release);
+    }
+  }
+  *out = p;
+  return VQAF_OK;
+}
+
+template <int MT, bool AK, bool BK_>
+int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  constexpr size_t smem = (size_t)GB_STAGES * (64 * MT + GB_BN) * GB_BK * 2;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<MT, AK, BK_>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  hipLaunchKernelGGL((gemm_bf16_kernel<MT, AK, BK_>), grid, dim3(2 * GB_THREADS), smem, st, g);
+  return hipGetLastError() == hipSuccess ? VQAF_OK : VQAF_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int vqaf_gemm_bf16_supported(long lda, int a_kmajor, long ldb, int b_kmajor, int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0) return 0;
+  if (lda % 8 != 0 || ldb % 8 != 0) return 0;                       // 16-byte chunks, 16-byte aligned rows
+  if (a_kmajor ? ((M + 7) / 8 * 8 > lda) : (K % 8 != 0 || K > lda)) return 0;
+  if (b_kmajor ? ((N + 7) / 8 * 8 > ldb) : (K % 8 != 0 || K > ldb)) return 0;
+  return 1;
+}
+
+extern "C" int vqaf_gemm_bf16(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor,
+                              int M, int N, int K, const void* bias, int bias_dtype, void* C, long ldc,
+                              int c_dtype, int accumulate, float* colsum, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(A && B && C, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(c_dtype) && (bias == nullptr || vqaf_dtype_ok(bias_dtype)), VQAF_E_DTYPE);
+  VQAF_REQUIRE(M > 0 && N > 0 && K > 0 && ldc >= N, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_gemm_bf16_supported(lda, a_kmajor, ldb, b_kmajor, M, N, K), VQAF_E_ALIGN);
+  VQAF_REQUIRE(vqaf_aligned16(A) && vqaf_aligned16(B), VQAF_E_ALIGN);
+  VQAF_REQUIRE(!(c_dtype == VQAF_BF16 && (accumulate || colsum != nullptr)), VQAF_E_DTYPE);
+  VQAF_REQUIRE(colsum == nullptr || a_kmajor, VQAF_E_SHAPE);
+  const unsigned int* zeros = nullptr;
+  const int rc = zero_block_on_current_device(&zeros);
+  if (rc != VQAF_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  // tile height: 128 rows unless that leaves the chip half empty
+  const long tiles128 = (long)((M + 127) / 128) * ((N + GB_BN - 1) / GB_BN);
+  const int MT = (tiles128 >= 200 || M > 4096) ? 2 : 1;
+  const int BM = 64 * MT;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + GB_BN - 1) / GB_BN;
+  VQAF_REQUIRE((long)tiles_m * tiles_n < (1l << 30), VQAF_E_SHAPE);
+  dim3 grid((unsigned)(tiles_m * tiles_n), 1, 1);
+  // 8 equal regions of the tile grid, as square as the tile counts allow
+  int reg_m = 0, reg_n = 0;
+  {
+    const int cand[4][2] = {{2, 4}, {4, 2}, {1, 8}, {8, 1}};
+    long best = -1;
+    for (const auto& c : cand) {
+      if (tiles_m % c[0] != 0 || tiles_n % c[1] != 0) continue;
+      // operand bytes one region streams: its A panels + its B panels
+      const long cost = (long)(tiles_m / c[0]) * BM + (long)(tiles_n / c[1]) * GB_BN;
+      if (best < 0 || cost < best) { best = cost; reg_m = c[0]; reg_n = c[1]; }
+    }
+  }
+  // few tiles and an f32 output: split the contraction over workgroups (f32 atomics into a zeroed
+  // output); each split keeps at least four k-steps
+  int splits = 1;
+  if (c_dtype == VQAF_F32) {
+    const long tiles = (long)grid.x;
+    while (tiles * splits < 192 && splits < 8 && K / (splits * 2) >= 4 * GB_BK) splits *= 2;
+  }
+  const int k_per_split = ((K + splits - 1) / splits + GB_BK - 1) / GB_BK * GB_BK;
+  grid.z = splits;
+  GemmArgs g;
+  g.A = reinterpret_cast<const bf16_t*>(A);
+  g.B = reinterpret_cast<const bf16_t*>(B);
+  g.bias = bias;
+  g.C = C;
+  g.colsum = colsum;
+  g.zeros = zeros;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K;
+  g.k_per_split = k_per_split;
+  g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.reg_m = reg_m; g.reg_n = reg_n;
+  g.bias_bf16 = bias_dtype == VQAF_BF16 ? 1 : 0;
+  if (c_dtype == VQAF_BF16) g.out_mode = GB_OUT_BF16;
+  else if (splits > 1) g.out_mode = GB_OUT_F32_ATOMIC;
+  else g.out_mode = accumulate ? GB_OUT_F32_ACC : GB_OUT_F32;
+  if (splits > 1 && !accumulate) {  // atomics add into the output: start it from zero
+    if (ldc == N) {
+      if (hipMemsetAsync(C, 0, (size_t)M * N * 4, st) != hipSuccess) return VQAF_E_LAUNCH;
+    } else {
+      if (hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, st) != hipSuccess) return VQAF_E_LAUNCH;
+    }
+    if (colsum != nullptr && hipMemsetAsync(colsum, 0, (size_t)M * 4, st) != hipSuccess) return VQAF_E_LAUNCH;
+  }
+  if (splits > 1 && bias != nullptr) return VQAF_E_SHAPE;  // a bias would be added once per split
+#define VQAF_GB(MTv)                                                                 \
+  do {                                                                               \
+    if (a_kmajor && b_kmajor) return launch_gemm<MTv, true, true>(g, grid, st);      \
+    if (!a_kmajor && b_kmajor) return launch_gemm<MTv, false, true>(g, grid, st);    \
+    if (!a_kmajor && !b_kmajor) return launch_gemm<MTv, false, false>(g, grid, st);  \
+    return launch_gemm<MTv, true, false>(g, grid, st);                               \
+  } while (0)
+  if (MT == 2) VQAF_GB(2);
+  VQAF_GB(1);
+#undef VQAF_GB
+}

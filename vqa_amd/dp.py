@@ -113,10 +113,19 @@ class _GhostLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias, tape):
         w = _as_dtype(weight, x.dtype, tape.shadow)
         b = None if bias is None else _as_dtype(bias, x.dtype, tape.shadow)
-        y = F.linear(x, w, b)
+        Bn, In = x.shape
+        Out = w.shape[0]
+        xc = x.contiguous()
+        if x.dtype == torch.bfloat16 and w.is_contiguous() and \
+                ops.gemm_bf16_supported(In, False, In, False, Bn, Out, In):
+            # y = x W^T + b on the library's own bf16 MFMA GEMM (bias in the epilogue)
+            y = torch.empty(Bn, Out, dtype=torch.bfloat16, device=x.device)
+            ops.gemm_bf16(xc, False, w, False, Bn, Out, In, y, bias=b)
+        else:
+            y = F.linear(x, w, b)
         ctx.save_for_backward(w)
         ctx.tape = tape
-        tape.a = x.detach()
+        tape.a = xc.detach()
         return y
 
     @staticmethod
@@ -124,7 +133,16 @@ class _GhostLinear(torch.autograd.Function):
         (w,) = ctx.saved_tensors
         gy = gy.contiguous()
         ctx.tape.g = gy
-        gx = gy.matmul(w) if ctx.needs_input_grad[0] else None
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None
+        Bn, Out = gy.shape
+        In = w.shape[1]
+        if gy.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.is_contiguous() and \
+                ops.gemm_bf16_supported(Out, False, In, True, Bn, In, Out):
+            gx = torch.empty(Bn, In, dtype=torch.bfloat16, device=gy.device)
+            ops.gemm_bf16(gy, False, w, True, Bn, In, Out, gx)
+        else:
+            gx = gy.matmul(w)
         return gx, None, None, None
 
 
@@ -489,12 +507,17 @@ class DPOptimizer:
                 sw = self._slice(S, m.weight)
                 sb = self._slice(S, m.bias) if m.bias is not None else None
                 probe = f"clipped_sum_linear:{g.shape[1]}x{a.shape[1]}"
-                ops._probe(probe, "begin")
-                check(lib.vqaf_clipped_sum_linear(ptr(a), ptr(g), None if prescaled else ptr(coef), B,
-                                                  a.shape[1], g.shape[1],
-                                                  dtype_code(g), 0, ptr(sw), ptr(sb), st),
-                      "vqaf_clipped_sum_linear")
-                ops._probe(probe, "end")
+                In_, Out_ = a.shape[1], g.shape[1]
+                if prescaled and g.dtype == torch.bfloat16 and a.dtype == torch.bfloat16 and \
+                        ops.gemm_bf16_supported(Out_, True, In_, True, Out_, In_, B):
+                    # S = G^T A with the batch as the contraction index; Sb = column sums of G
+                    ops.gemm_bf16(g, True, a, True, Out_, In_, B, sw.view(Out_, In_), colsum=sb, name=probe)
+                else:
+                    ops._probe(probe, "begin")
+                    check(lib.vqaf_clipped_sum_linear(ptr(a), ptr(g), None if prescaled else ptr(coef), B,
+                                                      In_, Out_, dtype_code(g), 0, ptr(sw), ptr(sb), st),
+                          "vqaf_clipped_sum_linear")
+                    ops._probe(probe, "end")
             else:
                 check(lib.vqaf_clipped_sum_affine(ptr(a), ptr(g), None if prescaled else ptr(coef), B, g.shape[1],
                                                   dtype_code(g), 0, ptr(self._slice(S, m.weight)),

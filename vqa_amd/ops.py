@@ -619,6 +619,29 @@ def cross_entropy_mean(logits: torch.Tensor, targets: torch.Tensor) -> torch.Ten
     return _MeanCE.apply(logits, targets)
 
 
+def gemm_bf16_supported(lda: int, a_kmajor: bool, ldb: int, b_kmajor: bool, M: int, N: int, K: int) -> bool:
+    return bool(load().vqaf_gemm_bf16_supported(lda, int(a_kmajor), ldb, int(b_kmajor), M, N, K))
+
+
+@torch.no_grad()
+def gemm_bf16(A: torch.Tensor, a_kmajor: bool, B: torch.Tensor, b_kmajor: bool, M: int, N: int, K: int,
+              out: torch.Tensor, bias: Optional[torch.Tensor] = None, accumulate: bool = False,
+              colsum: Optional[torch.Tensor] = None, name: Optional[str] = None) -> torch.Tensor:
+    """out (M,N) = op(A) op(B) (+ bias) on bf16 MFMA (vqaf_gemm_bf16); A, B are 2-D bf16 tensors whose
+    second stride is 1 (row pitch = first stride), out f32 or bf16."""
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.stride(1) == 1 and B.stride(1) == 1
+    assert out.stride(1) == 1
+    if name is not None:
+        _probe(name, "begin")
+    check(load().vqaf_gemm_bf16(A.data_ptr(), A.stride(0), int(a_kmajor), B.data_ptr(), B.stride(0), int(b_kmajor),
+                                M, N, K, ptr(bias), dtype_code(bias) if bias is not None else 0, out.data_ptr(),
+                                out.stride(0), dtype_code(out), int(accumulate), ptr(colsum),
+                                stream_ptr(A.device)), "vqaf_gemm_bf16")
+    if name is not None:
+        _probe(name, "end")
+    return out
+
+
 def keep_count(n_tokens: int, prune_ratio: float) -> int:
     """k = max(1, int(N * (1 - prune_ratio))) in Python double arithmetic (utils/fusion.py:41)."""
     return max(1, int(n_tokens * (1 - prune_ratio)))
