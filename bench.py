@@ -190,23 +190,36 @@ def prune_mix_sweep(dev, dtype):
     seqs = [torch.randn(B, N, D, device=dev, generator=gen).to(dtype) for _ in range(6)]
     w = torch.rand(B, N, device=dev, generator=gen)
     out = {}
-    for keep in (0.25, 0.5, 0.75, 0.9):
-        K = ops.keep_count(N, 1 - keep)
+
+    def two_launch(seq, K):
+        idx, _b = ops.topk_indices(w, K, need_bottom=False)
+        ops.gather_mix(seq, idx, 0.05)
+
+    def one_launch(seq, K):
+        ops.prune_mix(seq, w, K, 0.05)
+
+    def timed(fn, K):
         for _ in range(3):
-            idx, _b = ops.topk_indices(w, K, need_bottom=False)
-            ops.gather_mix(seqs[0], idx, 0.05)
+            fn(seqs[0], K)
         reps = 24
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for r in range(reps):
-            idx, _b = ops.topk_indices(w, K, need_bottom=False)
-            ops.gather_mix(seqs[r % len(seqs)], idx, 0.05)
+            fn(seqs[r % len(seqs)], K)
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        return e0.elapsed_time(e1) / reps
+
+    fused_ok = ops.prune_mix_supported(N, D, dtype)
+    for keep in (0.25, 0.5, 0.75, 0.9):
+        K = ops.keep_count(N, 1 - keep)
         nbytes = B * (N * D * s + N * 4 + (K + 1) * D * s + K * 8)
+        ms2 = timed(two_launch, K)
+        ms = timed(one_launch, K) if fused_ok else ms2
         out[f"keep_{keep}"] = {"ms": round(ms, 5), "GB/s": round(nbytes / ms / 1e6, 1),
-                               "frac_of_8TBs": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                               "frac_of_8TBs": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                               "launches": 1 if fused_ok else 2,
+                               "two_launch_ms": round(ms2, 5)}
     return out
 
 
@@ -374,7 +387,7 @@ def main():
         lo, hi = vdist.shard_range(args.batch, rank, world)
         local_b, logical_b = hi - lo, args.batch
 
-    probe = Probe("gather_mix_pool_multi", "clipped_sum_linear:")
+    probe = Probe("gather_mix_pool_multi", "fused_prune_pool", "clipped_sum_linear:")
     ops.PROBE = probe
     dt, launch, eager_ms = run_job(args, dev, dtype, rank, world, local_b, logical_b, probe)
     ops.PROBE = None
@@ -393,19 +406,40 @@ def main():
     if rank == 0:
         s = 2 if dtype == torch.bfloat16 else 4
         K = ops.keep_count(N_VIS, 1 - KEEP)
-        # algorithmic bytes of the pooled prune+mix launch (vision and text tokens in one launch):
-        # every token row read once, the keep indices read, one pooled row written per modality
         Kt = ops.keep_count(N_TXT, 1 - KEEP)
-        alg_bytes = local_b * ((N_VIS * D * s + K * 8 + D * s) + (N_TXT * D * s + Kt * 8 + D * s))
-        k_ms = probe.mean_ms("gather_mix_pool_multi")
-        achieved = alg_bytes / k_ms / 1e6 if k_ms > 0 else 0.0
+        H = 8
         copy_gbs = copy_rate_gbs(dev)
         traffic = None
-        try:  # HBM bytes per launch from the PMC passes kept under profiles/ (same shape only)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+        fused = probe.mean_ms("fused_prune_pool") > 0
+        if fused:
+            # One launch scores, selects and pools both modalities.  Algorithmic bytes per sample and
+            # modality in the two-pass accounting of a fused score+prune (top-k needs every score
+            # before the first row can be pooled, so the tokens are read twice: N*D*s each pass),
+            # plus the folded queries H*D*4, the keep indices K*8 and one pooled row D*s.
+            # `one_pass_bytes` counts the tokens once (what HBM itself must deliver when the second
+            # pass is served on-die).
+            kname = "fused_prune_pool_kernel (scoring + selection + pooled prune/mix, vision + text tokens)"
+            k_ms = probe.mean_ms("fused_prune_pool")
+            per = lambda n, k, passes: passes * n * D * s + H * D * 4 + k * 8 + D * s  # noqa: E731
+            alg_bytes = local_b * (per(N_VIS, K, 2) + per(N_TXT, Kt, 2))
+            one_pass = local_b * (per(N_VIS, K, 1) + per(N_TXT, Kt, 1))
+            pmc_file, pmc_key = "r02_pmc_fused.json", "fused_prune_pool_kernel<16> (both)"
+            pmc_field = "fabric_bytes_per_launch"
+        else:
+            # separate launches (f32 tokens, unsupported widths): the pooled prune+mix launch, every
+            # token row read once, the keep indices read, one pooled row written per modality
+            kname = "gather_mix_pool_multi_kernel (prune+mix, vision + text tokens)"
+            k_ms = probe.mean_ms("gather_mix_pool_multi")
+            alg_bytes = local_b * ((N_VIS * D * s + K * 8 + D * s) + (N_TXT * D * s + Kt * 8 + D * s))
+            one_pass = alg_bytes
+            pmc_file, pmc_key = "r01_pmc_traffic.json", "gather_mix_pool_multi_kernel<true, true, 32>"
+            pmc_field = "hbm_bytes_per_launch"
+        achieved = alg_bytes / k_ms / 1e6 if k_ms > 0 else 0.0
+        try:  # fabric-side bytes per launch from the PMC passes kept under profiles/ (same shape only)
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
                 pmc = json.load(fh)
             if local_b == 1024 and args.dtype == "bf16":
-                traffic = pmc["kernels"]["gather_mix_pool_multi_kernel<true, true, 32>"]["hbm_bytes_per_launch"]
+                traffic = pmc["kernels"][pmc_key][pmc_field]
         except (OSError, KeyError, ValueError):
             traffic = None
         timing = ("stream events around the launch in eagerly launched steps right after the timed region "
@@ -435,10 +469,12 @@ def main():
                                    f"CoAttention pruning keep 0.5, {N_VIS} vision + {N_TXT} text tokens x {D}, "
                                    f"{C} classes; encoders bypassed",
                        "global_batch": logical_b, "per_gpu_batch": local_b, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": "gather_mix_pool_multi_kernel (prune+mix, vision + text tokens)",
+            "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(k_ms, 5), "algorithmic_bytes": alg_bytes,
+                         "one_pass_bytes": one_pass,
+                         "one_pass_GBs": round(one_pass / k_ms / 1e6, 1) if k_ms > 0 else 0.0,
                          "kernel_timing": timing, "copy_rate_same_run_GBs": round(copy_gbs, 1),
                          "frac_of_copy_rate": round(achieved / copy_gbs, 4) if copy_gbs > 0 else None},
             "mfma": mfma,

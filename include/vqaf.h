@@ -265,6 +265,21 @@ int vqaf_gather_mix_pool_bwd_multi(const void* grad_out, int ld_out, int g_dtype
                                    const vqaf_pool_bwd_mod* mods_host, int n_mod, int B, int D,
                                    int dtype, vqaf_stream_t stream);
 
+/* PrivacyAwareTokenPruning.forward (utils/fusion.py:26-94) in ONE launch: vqaf_select on given
+ * weights followed by vqaf_gather_mix, without the gather waiting for a ranking launch: every lane
+ * issues all row loads of its (sample, 128-column slice) first and the ranking runs while they are
+ * in flight.  w (B,N) f32 attention weights; out (B, K + (alpha > 0), D); idx_out (B,K) int64 keep
+ * indices.  Same results as vqaf_select + vqaf_gather_mix: same ranking, same draws for the same
+ * rng states (noise_counter_offset as in vqaf_fused_mod), kept rows bit-exact copies.
+ * vqaf_prune_mix_supported: N <= 592 for bf16 tokens, N <= 208 for f32 tokens (a lane keeps its
+ * rows in registers); other sizes return VQAF_E_SHAPE and callers use the two entry points. */
+int vqaf_prune_mix_supported(int N, int D, int dtype);
+int vqaf_prune_mix(const void* seq, const float* w, int B, int N, int K, int D, int dtype, int adv_mode,
+                   int k_adv, const int64_t* pos, const int64_t* src, const uint64_t* sel_rng_state,
+                   uint64_t salt, const float* noise, int noise_kind, float noise_scale,
+                   const uint64_t* noise_rng_state, int noise_counter_offset, float alpha, int out_dtype,
+                   void* out, int64_t* idx_out, vqaf_stream_t stream);
+
 /* The whole pruning branch of a modality -- vqaf_head_scores, vqaf_select and
  * vqaf_gather_mix_pool -- in ONE launch, one workgroup per sample (utils/fusion.py:234-240 with
  * :253; :243-249 with :254; :159-170).  The second pass over a sample's tokens follows the first

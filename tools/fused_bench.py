@@ -1,5 +1,4 @@
-"""Timing of the one-launch pruning branch (developer tool): vision only, text only, both.
-VQAF_FUSED_DBG bit mask skips phases inside the kernel (1 scoring pass, 2 selection, 4 pooling pass)."""
+"""Timing of the one-launch pruning branch (developer tool): vision only, text only, both."""
 import os
 import sys
 

@@ -75,7 +75,7 @@ __device__ __forceinline__ void unpack_bf16x8(const u32x4 r, float (&v)[8]) {
 template <int STEPS>
 __global__ void __launch_bounds__(FU_THREADS, (STEPS <= 16 ? 4 : 2))
 fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, const uint64_t* __restrict__ sel_rng,
-                        void* __restrict__ out, int ld_out, int out_bf16, int dbg) {
+                        void* __restrict__ out, int ld_out, int out_bf16) {
   // Modalities along y: every long (vision) sample is dispatched before the short (text) ones,
   // which then fill the tail of the launch.  Measured alternatives, both slower: alternating the
   // modalities in dispatch order (+22 us at B = 1024: the last long samples start late), and one
@@ -138,7 +138,7 @@ fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, const uint64_t* __rest
     if (tid < 4) misc[tid] = 0;
     __syncthreads();
     const bf16_t* ubl = &ub[col * PITCH + 8 * kg];
-    for (; tile < ((dbg & 1) ? 0 : N); tile += 16 * FU_WAVES) {
+    for (; tile < N; tile += 16 * FU_WAVES) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int st = 0; st < HS; ++st) {
@@ -171,10 +171,6 @@ fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, const uint64_t* __rest
     seed = sel_rng[0] + M.salt;
     counter = sel_rng[1];
   }
-  if (dbg & 2) {
-    for (int n = tid; n < N; n += FU_THREADS) L.rank[n] = n;
-    __syncthreads();
-  } else
   select_core(L, H, N, K, NP, M.adv_mode, k_adv, M.NPK, M.NPR,
               M.pos ? M.pos + (size_t)b * k_adv : nullptr, M.src ? M.src + (size_t)b * k_adv : nullptr,
               seed, counter, (unsigned long long)b, M.w_out ? M.w_out + (size_t)b * N : nullptr,
@@ -182,9 +178,7 @@ fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, const uint64_t* __rest
   for (int n = tid; n < N; n += FU_THREADS) mult[n] = 0;
   __syncthreads();
   for (int j = tid; j < K; j += FU_THREADS) {
-    const int n = L.rank[j];
-    M.idx_out[(size_t)b * K + j] = (int64_t)n;
-    atomicAdd(&mult[n], 1);
+    atomicAdd(&mult[L.rank[j]], 1);  // (the keep list goes out after pass 2: a barrier waits for stores)
   }
   __syncthreads();
   {
@@ -216,7 +210,7 @@ fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, const uint64_t* __rest
       }
     };
     load_batch(cur, g);
-    for (int n0 = g; n0 < ((dbg & 4) ? 0 : N); n0 += U * ROWS) {
+    for (int n0 = g; n0 < N; n0 += U * ROWS) {
       const bool more = n0 + U * ROWS < N;
       load_batch(nxt, n0 + U * ROWS);
 #pragma unroll
@@ -240,6 +234,7 @@ fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, const uint64_t* __rest
       }
     }
   }
+  for (int j = tid; j < K; j += FU_THREADS) M.idx_out[(size_t)b * K + j] = (int64_t)L.rank[j];
   // noise: one draw per keep slot and element, addressed exactly as the unfused kernels address it
   if (M.noise != nullptr) {
     for (int j = g; j < K; j += ROWS) {
@@ -337,9 +332,8 @@ extern "C" int vqaf_fused_prune_pool_multi(const vqaf_fused_mod* mods_host, int 
   const dim3 grid(B, n_mod), block(FU_THREADS);
   hipStream_t st = (hipStream_t)stream;
   const int obf = out_dtype == VQAF_BF16 ? 1 : 0;
-  static const int dbg = [] { const char* e = getenv("VQAF_FUSED_DBG"); return e ? atoi(e) : 0; }();
 #define VQAF_FU(S) \
-  hipLaunchKernelGGL(fused_prune_pool_kernel<S>, grid, block, smem, st, mods, n_mod, H, sel_rng_state, out, ld_out, obf, dbg)
+  hipLaunchKernelGGL(fused_prune_pool_kernel<S>, grid, block, smem, st, mods, n_mod, H, sel_rng_state, out, ld_out, obf)
   switch (D / 32) {
     case 2: VQAF_FU(2); break;
     case 4: VQAF_FU(4); break;

@@ -14,8 +14,8 @@ __device__ __forceinline__ unsigned int order_key(float w) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// Sorts keys[0..NP) descending; NP a power of two; all threads of the block take part.
-__device__ inline void bitonic_sort_desc(unsigned long long* keys, int NP) {
+// Bitonic network through LDS, one barrier per step: any NP, any block size.
+__device__ inline void bitonic_sort_desc_lds(unsigned long long* keys, int NP) {
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int k = 2; k <= NP; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -31,6 +31,138 @@ __device__ inline void bitonic_sort_desc(unsigned long long* keys, int NP) {
       }
       __syncthreads();
     }
+  }
+}
+
+// The same network with the keys in registers.  Thread t holds elements t*E .. t*E+E-1, so a step
+// of distance j is an exchange between registers (j < E), between lanes of a wave (j < 64*E: DPP
+// moves within a row of 16 lanes, a cross-lane permute beyond) or between waves (through LDS, the
+// only steps that need a barrier: 3 of the 55 for 1024 keys on 256 threads).  A step through LDS
+// costs a wave two dependent LDS round trips; the register steps cost a handful of ALU
+// instructions, which is what makes ranking 577 weights take microseconds rather than tens.
+template <int CTRL>
+__device__ __forceinline__ unsigned int sel_dpp_all(unsigned int src) {  // every lane receives a value
+  return (unsigned int)__builtin_amdgcn_mov_dpp((int)src, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL, int BANK>
+__device__ __forceinline__ unsigned int sel_dpp_banks(unsigned int old, unsigned int src) {
+  return (unsigned int)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, BANK, false);
+}
+template <int D>
+__device__ __forceinline__ unsigned int sel_lane_xor32(unsigned int x) {
+  static_assert(D == 1 || D == 2 || D == 4 || D == 8, "DPP reaches lanes of the same row of 16");
+  if constexpr (D == 1) {
+    return sel_dpp_all<0xB1>(x);  // quad_perm [1,0,3,2]
+  } else if constexpr (D == 2) {
+    return sel_dpp_all<0x4E>(x);  // quad_perm [2,3,0,1]
+  } else if constexpr (D == 4) {
+    const unsigned int t = sel_dpp_banks<0x104, 0x5>(x, x);  // row_shl:4 into banks 0,2 (lane <- lane + 4)
+    return sel_dpp_banks<0x114, 0xA>(t, x);                  // row_shr:4 into banks 1,3 (lane <- lane - 4)
+  } else {
+    return sel_dpp_all<0x128>(x);  // row_ror:8
+  }
+}
+// One step between lanes D apart.  take_max: this lane keeps the larger key of the pair.
+template <int E, int D>
+__device__ __forceinline__ void sel_lane_step(unsigned long long (&v)[E], bool take_max) {
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    if constexpr (D < 16) {
+      const unsigned int lo = sel_lane_xor32<D>((unsigned int)v[r]), hi = sel_lane_xor32<D>((unsigned int)(v[r] >> 32));
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      v[r] = ((o > v[r]) == take_max) ? o : v[r];
+    } else {
+      // Rows of 16 lanes (D = 16) or wave halves (D = 32) trade places between two copies of the
+      // key: afterwards the first copy holds the pair's member from the even row (lower half) and
+      // the second the one from the odd row (upper half), on both lanes of the pair; each lane then
+      // picks the larger or the smaller of the two.
+      const unsigned int xl = (unsigned int)v[r], xh = (unsigned int)(v[r] >> 32);
+      unsigned int al, bl, ah, bh;
+      if constexpr (D == 16) {
+        const auto l = __builtin_amdgcn_permlane16_swap(xl, xl, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(xh, xh, false, false);
+        al = l[0]; bl = l[1]; ah = h[0]; bh = h[1];
+      } else {
+        static_assert(D == 32, "lane distance");
+        const auto l = __builtin_amdgcn_permlane32_swap(xl, xl, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(xh, xh, false, false);
+        al = l[0]; bl = l[1]; ah = h[0]; bh = h[1];
+      }
+      const unsigned long long a = ((unsigned long long)ah << 32) | al, c = ((unsigned long long)bh << 32) | bl;
+      v[r] = ((a > c) == take_max) ? a : c;
+    }
+  }
+}
+
+template <int E>
+__device__ inline void bitonic_sort_desc_regs(unsigned long long* keys, int NP) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int e0 = tid * E;
+  const bool mine = e0 < NP;  // NP is a multiple of E; threads beyond the keys carry padding
+  unsigned long long v[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) v[r] = mine ? keys[e0 + r] : 0ull;
+  for (int k = 2; k <= NP; k <<= 1) {
+    const bool desc = (e0 & k) == 0;  // for k >= E; the register steps below handle k < E themselves
+    for (int j = k >> 1; j >= 64 * E; j >>= 1) {  // partner in another wave
+      __syncthreads();
+      if (mine) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) keys[e0 + r] = v[r];
+      }
+      __syncthreads();
+      if (mine) {
+        const bool take_max = ((e0 & j) == 0) == desc;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const unsigned long long o = keys[(e0 + r) ^ j];
+          v[r] = ((o > v[r]) == take_max) ? o : v[r];
+        }
+      }
+    }
+    if (k >= 64 * E) sel_lane_step<E, 32>(v, ((lane & 32) == 0) == desc);
+    if (k >= 32 * E) sel_lane_step<E, 16>(v, ((lane & 16) == 0) == desc);
+    if (k >= 16 * E) sel_lane_step<E, 8>(v, ((lane & 8) == 0) == desc);
+    if (k >= 8 * E) sel_lane_step<E, 4>(v, ((lane & 4) == 0) == desc);
+    if (k >= 4 * E) sel_lane_step<E, 2>(v, ((lane & 2) == 0) == desc);
+    if (k >= 2 * E) sel_lane_step<E, 1>(v, ((lane & 1) == 0) == desc);
+#pragma unroll
+    for (int j = E >> 1; j >= 1; j >>= 1) {
+      if (k >= 2 * j) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          if ((r & j) == 0) {
+            const bool d = ((e0 + r) & k) == 0;
+            const unsigned long long a = v[r], c = v[r | j];
+            const bool swap = d ? (a < c) : (a > c);
+            v[r] = swap ? c : a;
+            v[r | j] = swap ? a : c;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();  // cross-wave partner reads of the last pass are done
+  if (mine) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) keys[e0 + r] = v[r];
+  }
+  __syncthreads();
+}
+
+// Sorts keys[0..NP) descending; NP a power of two; all threads of the block take part; the keys
+// are visible to the block on entry (a barrier has been passed) and again on return.
+__device__ inline void bitonic_sort_desc(unsigned long long* keys, int NP) {
+  const int nt = blockDim.x;
+  const int E = NP > nt ? NP / nt : 1;
+  if ((nt & 63) != 0 || E * nt < NP) return bitonic_sort_desc_lds(keys, NP);
+  switch (E) {
+    case 1: return bitonic_sort_desc_regs<1>(keys, NP);
+    case 2: return bitonic_sort_desc_regs<2>(keys, NP);
+    case 4: return bitonic_sort_desc_regs<4>(keys, NP);
+    case 8: return bitonic_sort_desc_regs<8>(keys, NP);
+    case 16: return bitonic_sort_desc_regs<16>(keys, NP);
+    default: return bitonic_sort_desc_lds(keys, NP);
   }
 }
 

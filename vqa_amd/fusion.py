@@ -96,9 +96,21 @@ class PrivacyAwareTokenPruning(nn.Module):
     def forward(self, seq, attn_weights, replace_positions=None, random_bottom=None, noise=None):
         """seq (B,N,D), attn_weights (B,1,N) or (B,N) -> (B,K+1,D) ((B,K,D) if mixup_alpha <= 0)."""
         B, N, D = seq.shape
+        noise_t, noise_type = self._noise_args(noise)
+        if (replace_positions is None) != (random_bottom is None):
+            raise ValueError("inject both replace_positions and random_bottom, or neither")
+        if attn_weights is not None and ops.prune_mix_supported(N, D, seq.dtype):
+            # one launch: the row loads do not wait for the ranking
+            k, k_adv = self.plan(N)
+            out, idx = ops.prune_mix(seq, attn_weights, k, float(self.mixup_alpha), k_adv=k_adv,
+                                     pos=replace_positions if k_adv else None,
+                                     src=random_bottom if k_adv else None, noise=noise_t,
+                                     noise_type=noise_type, noise_scale=float(self.noise_scale), rng=self.rng)
+            self.last_indices = idx
+            self._drew = k_adv > 0 and replace_positions is None
+            return out
         idx = self.select(attn_weights, N, replace_positions, random_bottom)
         self.last_indices = idx
-        noise_t, noise_type = self._noise_args(noise)
         return ops.gather_mix(seq, idx, float(self.mixup_alpha), noise=noise_t, noise_type=noise_type,
                               noise_scale=float(self.noise_scale), rng=self.rng)
 

@@ -319,6 +319,82 @@ def gather_mix(seq: torch.Tensor, idx: torch.Tensor, alpha: float, noise: Option
     return out
 
 
+def prune_mix_supported(n_tokens: int, width: int, dtype: torch.dtype) -> bool:
+    """Whether vqaf_prune_mix takes a (.., n_tokens, width) sequence of this dtype."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        return False
+    return bool(load().vqaf_prune_mix_supported(int(n_tokens), int(width),
+                                                _lib.BF16 if dtype == torch.bfloat16 else _lib.F32))
+
+
+class _PruneMix(torch.autograd.Function):
+    """Selection + gather + noise + mix token of one sequence in one launch (vqaf_prune_mix)."""
+
+    @staticmethod
+    def forward(ctx, seq, w, K, mode, k_adv, pos, src, rng_state, salt, noise, noise_kind, noise_scale,
+                noise_off, alpha, out_dtype):
+        B, N, D = seq.shape
+        seq_c = seq.contiguous()
+        kout = K + (1 if alpha > 0 else 0)
+        out = torch.empty(B, kout, D, dtype=out_dtype, device=seq.device)
+        idx = torch.empty(B, K, dtype=torch.int64, device=seq.device)
+        noise_c = noise.to(torch.float32).contiguous() if noise is not None else None
+        need_noise_state = noise_c is None and noise_kind != _lib.NOISE_NONE
+        check(load().vqaf_prune_mix(ptr(seq_c), ptr(w), B, N, K, D, dtype_code(seq_c), mode, k_adv,
+                                    ptr(pos) if mode == 1 else None, ptr(src) if mode == 1 else None,
+                                    ptr(rng_state) if mode == 2 else None, int(salt), ptr(noise_c), noise_kind,
+                                    float(noise_scale), ptr(rng_state) if need_noise_state else None,
+                                    int(noise_off), float(alpha), dtype_code(out), ptr(out), ptr(idx),
+                                    stream_ptr(seq.device)), "vqaf_prune_mix")
+        ctx.save_for_backward(idx)
+        ctx.meta = (B, N, K, D, float(alpha), seq.dtype)
+        ctx.mark_non_differentiable(idx)
+        return out, idx
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_idx):
+        (idx,) = ctx.saved_tensors
+        B, N, K, D, alpha, sdt = ctx.meta
+        g = grad_out.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        grad_seq = torch.empty(B, N, D, dtype=sdt, device=g.device)
+        check(load().vqaf_gather_mix_bwd(ptr(g), ptr(idx), alpha, B, N, K, D, dtype_code(g),
+                                         dtype_code(grad_seq), ptr(grad_seq), stream_ptr(g.device)),
+              "vqaf_gather_mix_bwd")
+        return (grad_seq,) + (None,) * 14
+
+
+def prune_mix(seq: torch.Tensor, weights: torch.Tensor, k: int, alpha: float, k_adv: int = 0,
+              pos: Optional[torch.Tensor] = None, src: Optional[torch.Tensor] = None,
+              noise: Optional[torch.Tensor] = None, noise_type: Optional[str] = None, noise_scale: float = 0.0,
+              rng: Optional[PhiloxState] = None, out_dtype: Optional[torch.dtype] = None, salt: int = 0):
+    """(out (B,K+1,D) or (B,K,D) if alpha <= 0, keep indices (B,K) int64) from attention weights in
+    ONE launch.  Same results and the same random streams as select_indices() followed by
+    gather_mix(): the adversarial draws come from the state's current counter, the noise from the
+    next one when both are drawn, and the state then advances once per stream used."""
+    if weights.dim() == 3:
+        weights = weights.squeeze(1)
+    w = weights.detach().to(torch.float32).contiguous()
+    mode = 0
+    if k_adv > 0:
+        mode = 1 if pos is not None else 2
+        if mode == 1:
+            pos, src = pos.to(torch.int64).contiguous(), src.to(torch.int64).contiguous()
+    kind = _noise_kind(noise_type) if noise is None else _lib.NOISE_NONE
+    draws_noise = kind != _lib.NOISE_NONE
+    state = None
+    if mode == 2 or draws_noise:
+        rng = rng or default_rng(seq.device)
+        state = rng.state
+    noise_off = 1 if (mode == 2 and draws_noise) else 0
+    out, idx = _PruneMix.apply(seq, w, int(k), mode, int(k_adv), pos, src, state, salt, noise, kind,
+                               noise_scale, noise_off, alpha, out_dtype or seq.dtype)
+    if state is not None:
+        rng.advance((1 if mode == 2 else 0) + (1 if draws_noise else 0))
+    return out, idx
+
+
 class _MeanPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
