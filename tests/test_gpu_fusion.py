@@ -346,6 +346,38 @@ def test_in_kernel_noise_statistics(dev):
         np.testing.assert_allclose(p.numpy(), a.mean(1).numpy(), rtol=1e-4, atol=1e-7)
 
 
+def test_in_kernel_noise_values_vs_host_generator(dev):
+    """Every in-kernel draw against the host restatement of the generator: the keep slot (b, j),
+    column d takes element ((b K + j) D + d) of stream (seed, counter).  The Gaussian flavour goes
+    through the hardware log / sqrt / sin / cos: absolute error below 2e-5 of a standard deviation
+    out to the largest value a 32-bit uniform can produce (6.66 sigma)."""
+    import philox_np
+    from vqa_amd import ops
+    B, N, D, K = 6, 40, 256, 17
+    seq = torch.zeros(B, N, D, device=dev)
+    idx = torch.arange(K, device=dev).repeat(B, 1)
+    for seed, adv in ((7, 0), (0xDEADBEEFCAFE, 3)):
+        rng = ops.PhiloxState(dev, seed=seed)
+        if adv:
+            rng.advance(adv)
+        g = ops.gather_mix(seq, idx, 0.0, noise_type="gaussian", noise_scale=1.0, rng=rng).cpu().numpy().reshape(-1)
+        want = philox_np.normal(rng.seed, adv, B * K * D)
+        assert np.abs(g - want).max() < 2e-5
+        rng = ops.PhiloxState(dev, seed=seed)
+        if adv:
+            rng.advance(adv)
+        u = ops.gather_mix(seq, idx, 0.0, noise_type="uniform", noise_scale=1.0, rng=rng).cpu().numpy().reshape(-1)
+        np.testing.assert_allclose(u, philox_np.uniform(rng.seed, adv, B * K * D), rtol=0, atol=1.2e-7)
+    # tails: a million draws hold the expected share beyond 3 and 4 sigma
+    big = torch.zeros(16, 130, 512, device=dev)
+    bidx = torch.arange(128, device=dev).repeat(16, 1)
+    z = ops.gather_mix(big, bidx, 0.0, noise_type="gaussian", noise_scale=1.0, rng=ops.PhiloxState(dev, seed=3))
+    n = z.numel()
+    for t, p in ((3.0, 2.6998e-3), (4.0, 6.334e-5)):
+        share = float((z.abs() > t).sum().item()) / n
+        assert abs(share - p) < 5 * (p / n) ** 0.5, (t, share)
+
+
 # ------------------------------------------------------------------ modules end to end
 @pytest.mark.parametrize("name", _names("coattn_"))
 def test_coattention_pruned_vs_golden(dev, name):

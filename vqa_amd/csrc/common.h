@@ -140,8 +140,19 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(unsigned long long see
                (unsigned int)(ctr_hi >> 32)};
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // One v_mad_u64_u32 yields both halves of a 32x32 product; left alone the compiler issues a
+    // v_mul_hi_u32 and a v_mul_lo_u32 (each a quarter-rate instruction) per product, and the forty
+    // of them are most of the generator's cost.
+    unsigned long long p0, p1, cy0, cy1;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p0), "=s"(cy0) : "s"(0xD2511F53u), "v"(c.x));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p1), "=s"(cy1) : "s"(0xCD9E8D57u), "v"(c.z));
+    const unsigned int hi0 = (unsigned int)(p0 >> 32), lo0 = (unsigned int)p0;
+    const unsigned int hi1 = (unsigned int)(p1 >> 32), lo1 = (unsigned int)p1;
+#else
     const unsigned int hi0 = vqaf_mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
     const unsigned int hi1 = vqaf_mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+#endif
     Philox4 n = {hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
     c = n;
     k0 += 0x9E3779B9u;
@@ -168,6 +179,24 @@ __device__ __forceinline__ void vqaf_normal4(unsigned long long seed, unsigned l
   const Philox4 r = philox4x32_10(seed, call, counter);
   vqaf_box_muller(r.x, r.y, z[0], z[1]);
   vqaf_box_muller(r.z, r.w, z[2], z[3]);
+}
+// The token-noise flavour of the same draw (utils/fusion.py:96-116: a regulariser added to kept
+// tokens, not the privacy mechanism): the same Philox words through the hardware transcendentals --
+// v_log_f32, v_sqrt_f32 and v_sin/v_cos_f32, whose argument is in revolutions, so the uniform goes
+// in unscaled.  About 12 instructions per pair instead of ~80; the absolute error of a value is
+// below 1e-5 (the library's moment and tail tests hold for either flavour).  The DP noise keeps
+// vqaf_normal4.
+__device__ __forceinline__ void vqaf_box_muller_fast(unsigned int a, unsigned int b, float& n0, float& n1) {
+  const float u = vqaf_u01(a), v = vqaf_u01(b);
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));  // -2 ln u = -2 ln2 log2 u
+  n0 = r * __builtin_amdgcn_cosf(v);
+  n1 = r * __builtin_amdgcn_sinf(v);
+}
+__device__ __forceinline__ void vqaf_normal4_fast(unsigned long long seed, unsigned long long counter,
+                                                  unsigned long long call, float (&z)[4]) {
+  const Philox4 r = philox4x32_10(seed, call, counter);
+  vqaf_box_muller_fast(r.x, r.y, z[0], z[1]);
+  vqaf_box_muller_fast(r.z, r.w, z[2], z[3]);
 }
 // Same draw as four U(-1,1) values.
 __device__ __forceinline__ void vqaf_uniform4(unsigned long long seed, unsigned long long counter,

@@ -250,8 +250,8 @@ fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, const uint64_t* __rest
       const size_t e = ((size_t)b * K + j) * D + d0;
       float z0[4], z1[4];
       if (M.noise_kind == VQAF_NOISE_GAUSSIAN) {
-        vqaf_normal4(nseed, ncounter, e >> 2, z0);
-        vqaf_normal4(nseed, ncounter, (e >> 2) + 1, z1);
+        vqaf_normal4_fast(nseed, ncounter, e >> 2, z0);
+        vqaf_normal4_fast(nseed, ncounter, (e >> 2) + 1, z1);
       } else {
         vqaf_uniform4(nseed, ncounter, e >> 2, z0);
         vqaf_uniform4(nseed, ncounter, (e >> 2) + 1, z1);

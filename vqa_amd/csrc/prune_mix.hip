@@ -76,8 +76,8 @@ __device__ __forceinline__ void pm_noise8(float (&v)[8], const float* noise, int
   } else if (noise_kind != VQAF_NOISE_NONE) {
     float z0[4], z1[4];
     if (noise_kind == VQAF_NOISE_GAUSSIAN) {
-      vqaf_normal4(seed, counter, e >> 2, z0);
-      vqaf_normal4(seed, counter, (e >> 2) + 1, z1);
+      vqaf_normal4_fast(seed, counter, e >> 2, z0);
+      vqaf_normal4_fast(seed, counter, (e >> 2) + 1, z1);
     } else {
       vqaf_uniform4(seed, counter, e >> 2, z0);
       vqaf_uniform4(seed, counter, (e >> 2) + 1, z1);

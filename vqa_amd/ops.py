@@ -349,10 +349,13 @@ class _PruneMix(torch.autograd.Function):
         ctx.save_for_backward(idx)
         ctx.meta = (B, N, K, D, float(alpha), seq.dtype)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
         return out, idx
 
     @staticmethod
     def backward(ctx, grad_out, _grad_idx):
+        if grad_out is None:
+            return (None,) * 15
         (idx,) = ctx.saved_tensors
         B, N, K, D, alpha, sdt = ctx.meta
         g = grad_out.contiguous()
@@ -592,11 +595,14 @@ class _FusedPrunePool(torch.autograd.Function):
         ctx.metas = metas
         ctx.B, ctx.ld, ctx.n_mod, ctx.per = B, ld, n_mod, per
         ctx.mark_non_differentiable(*idxs)
+        ctx.set_materialize_grads(False)  # no zero-filled int64 "gradients" for the index outputs
         return (out, *idxs)
 
     @staticmethod
     def backward(ctx, grad_out, *_unused):
         import ctypes
+        if grad_out is None:
+            return (None,) * (3 + ctx.per * ctx.n_mod)
         g = grad_out.contiguous()
         if g.dtype not in (torch.float32, torch.bfloat16):
             g = g.float()
@@ -688,7 +694,9 @@ class _MeanCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (grad,) = ctx.saved_tensors
-        return (grad * grad_out).to(ctx.in_dtype), None
+        # one launch: the product is rounded straight into the logits' dtype
+        out = torch.empty(grad.shape, dtype=ctx.in_dtype, device=grad.device)
+        return torch.mul(grad, grad_out, out=out), None
 
 
 def cross_entropy_mean(logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
