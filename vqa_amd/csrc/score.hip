@@ -200,6 +200,89 @@ head_scores_mfma_kernel(ScoreMods mods, int H, int tokb) {
   }
 }
 
+// f32 tokens on the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32 products, f32 sums).  Same
+// tiling as the bf16 kernel: a wave scores 16 tokens per tile, lane (token = lane & 15, kg = lane >> 4)
+// loads 16 bytes = columns 16 j + 4 kg .. + 3 of its token straight from HBM and feeds them to four
+// MFMAs, one column each; the B lane (head = lane & 15, kg) reads the same four columns of u from
+// LDS, so both operands agree on which k a step multiplies and no transposition is needed.  The tile
+// is loaded in sets of eight 16-byte loads that alternate between two register sets: the MFMAs of
+// one set run while the loads of the next (of this or of the wave's next tile) are in flight, at a
+// register count that lets four waves share a SIMD.  Heads beyond H multiply zeros.
+template <int STEPS>  // D = 16 * STEPS
+__global__ void __launch_bounds__(SC_THREADS)
+head_scores_mfma_f32_kernel(ScoreMods mods, int H, int tokb) {
+  constexpr int D = 16 * STEPS;
+  constexpr int HS = STEPS >= 16 ? 8 : STEPS / 2;  // 16-byte loads per register set
+  constexpr int Q = STEPS / HS;                    // sets per tile (even)
+  constexpr int PITCH = D + 4;
+  __shared__ __attribute__((aligned(16))) float ub[8 * PITCH];
+  const float* __restrict__ seq = reinterpret_cast<const float*>(mods.seq[blockIdx.z]);
+  const float* __restrict__ u = mods.u[blockIdx.z];
+  float* __restrict__ s = mods.s[blockIdx.z];
+  const int N = mods.N[blockIdx.z];
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * tokb;
+  if (t0 >= N) return;
+  const int t1 = min(N, t0 + tokb);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int col = lane & 15, kg = lane >> 4;
+  const float* seq_b = seq + (size_t)b * N * D + 4 * kg;
+
+  f32x4 ha[HS], hb[HS];
+  auto load_set = [&](f32x4 (&dst)[HS], int tile, int q) {
+    const int row = min(tile + col, N - 1);  // rows past the end re-read the last token; never stored
+    const float* xr = seq_b + (size_t)row * D + 16 * HS * q;
+#pragma unroll
+    for (int st = 0; st < HS; ++st) dst[st] = *reinterpret_cast<const f32x4*>(xr + 16 * st);
+  };
+  int tile = t0 + 16 * wave;
+  load_set(ha, tile, 0);
+  load_set(hb, tile, 1);
+  {
+    const float* ug = u + (size_t)b * H * D;
+    for (int c = threadIdx.x; c < H * (D / 4); c += SC_THREADS) {
+      const int h = c / (D / 4), k4 = c % (D / 4);
+      *reinterpret_cast<f32x4*>(&ub[h * PITCH + 4 * k4]) = *reinterpret_cast<const f32x4*>(ug + (size_t)h * D + 4 * k4);
+    }
+  }
+  __syncthreads();
+  const bool head = col < H;
+  const float* ubl = &ub[(head ? col : 0) * PITCH + 4 * kg];
+  f32x4 acc;
+  auto multiply = [&](const f32x4 (&x)[HS], int q) {
+#pragma unroll
+    for (int st = 0; st < HS; ++st) {
+      f32x4 bf = *reinterpret_cast<const f32x4*>(ubl + 16 * (HS * q + st));
+      if (!head) bf = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[st].x, bf.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[st].y, bf.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[st].z, bf.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[st].w, bf.w, acc, 0, 0, 0);
+    }
+  };
+  for (; tile < t1; tile += 16 * SC_WAVES) {
+    const int next = tile + 16 * SC_WAVES;
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    // u is read from LDS again for every tile: hoisted out of this loop it would take 8 * STEPS
+    // registers and halve the waves per SIMD
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < Q; q += 2) {
+      // every load is unconditional (rows clamped), so the waits stay counted
+      multiply(ha, q);
+      if (q + 2 < Q) load_set(ha, tile, q + 2); else load_set(ha, next, 0);
+      multiply(hb, q + 1);
+      if (q + 3 < Q) load_set(hb, tile, q + 3); else load_set(hb, next, 1);
+    }
+    // C/D layout: column = lane & 15, row = 4 * (lane >> 4) + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tok = tile + 4 * kg + r;
+      if (head && tok < t1) s[((size_t)b * N + tok) * H + col] = acc[r];
+    }
+  }
+}
+
 // w[b,n] = (1/H) sum_h exp(s[b,n,h] - max_h) / sum_n exp(s[b,n,h] - max_h).
 // One workgroup per sample; s of one sample (N*H*4 bytes) is L2-resident, so the three
 // passes re-read it from cache.
@@ -294,6 +377,10 @@ static int launch_scores_mfma(const ScoreMods& mods, int n, int B, int Nmax, int
 static bool mfma_steps_ok(int D) {
   return D == 64 || D == 128 || D == 256 || D == 512 || D == 768 || D == 1024;
 }
+static bool mfma_f32_ok(int D, int H) {  // two half tiles of D/32 16-byte registers per lane
+  return H <= 8 && (D == 64 || D == 128 || D == 256 || D == 512);
+}
+static int launch_scores_mfma_f32(const ScoreMods& mods, int n, int B, int Nmax, int D, int H, hipStream_t st);
 
 extern "C" int vqaf_head_scores(const void* seq, const float* u, int B, int N, int D, int H,
                                 int dtype, float* s, vqaf_stream_t stream) {
@@ -309,6 +396,14 @@ extern "C" int vqaf_head_scores(const void* seq, const float* u, int B, int N, i
     mods.s[0] = s;
     mods.N[0] = N;
     return launch_scores_mfma(mods, 1, B, N, D, H, (hipStream_t)stream);
+  }
+  if (dtype == VQAF_F32 && mfma_f32_ok(D, H)) {
+    ScoreMods mods = {};
+    mods.seq[0] = reinterpret_cast<const bf16_t*>(seq);  // the f32 kernel reads it as float
+    mods.u[0] = u;
+    mods.s[0] = s;
+    mods.N[0] = N;
+    return launch_scores_mfma_f32(mods, 1, B, N, D, H, (hipStream_t)stream);
   }
   const int HP = pad_heads(H);
   const int CH = (D + 511) / 512;
@@ -369,13 +464,30 @@ static int launch_scores_mfma(const ScoreMods& mods, int n, int B, int Nmax, int
   VQAF_LAUNCH_CHECK();
 }
 
+static int launch_scores_mfma_f32(const ScoreMods& mods, int n, int B, int Nmax, int D, int H, hipStream_t st) {
+  int tokb = 64;
+  if ((long)B * ((Nmax + 127) / 128) >= 512) tokb = 128;
+  if ((long)B * ((Nmax + 255) / 256) >= 1024) tokb = 256;
+  const dim3 grid((Nmax + tokb - 1) / tokb, B, n), block(SC_THREADS);
+#define VQAF_HSF(S) hipLaunchKernelGGL(head_scores_mfma_f32_kernel<S>, grid, block, 0, st, mods, H, tokb)
+  switch (D / 16) {
+    case 4: VQAF_HSF(4); break;
+    case 8: VQAF_HSF(8); break;
+    case 16: VQAF_HSF(16); break;
+    default: VQAF_HSF(32); break;
+  }
+#undef VQAF_HSF
+  VQAF_LAUNCH_CHECK();
+}
+
 extern "C" int vqaf_head_scores_multi(const vqaf_scores_desc* descs_host, int n, int B, int D, int H,
                                       int dtype, vqaf_stream_t stream) {
   VQAF_ENTRY();
   VQAF_REQUIRE(descs_host != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(n > 0 && n <= SC_MAX_MODS && B > 0 && B <= 65535 && D > 0 && H > 0, VQAF_E_SHAPE);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
-  if (!(dtype == VQAF_BF16 && H <= 8 && mfma_steps_ok(D))) {
+  const bool f32_mfma = dtype == VQAF_F32 && mfma_f32_ok(D, H);
+  if (!(dtype == VQAF_BF16 && H <= 8 && mfma_steps_ok(D)) && !f32_mfma) {
     for (int i = 0; i < n; ++i) {  // other shapes: one launch per set
       const int rc = vqaf_head_scores(descs_host[i].seq, descs_host[i].u, B, descs_host[i].N, D, H, dtype,
                                       descs_host[i].s, stream);
@@ -396,6 +508,7 @@ extern "C" int vqaf_head_scores_multi(const vqaf_scores_desc* descs_host, int n,
     mods.N[i] = d.N;
     nmax = d.N > nmax ? d.N : nmax;
   }
+  if (f32_mfma) return launch_scores_mfma_f32(mods, n, B, nmax, D, H, (hipStream_t)stream);
   return launch_scores_mfma(mods, n, B, nmax, D, H, (hipStream_t)stream);
 }
 
