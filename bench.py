@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skip the fp32 tier sub-measurement")
     ap.add_argument("--cpu-sample", type=int, default=64)
     return ap.parse_args()
 
@@ -223,6 +224,66 @@ def prune_mix_sweep(dev, dtype):
     return out
 
 
+def dense_leg(dev, dtype):
+    """The unpruned branch (dense single-query cross-attention, utils/fusion.py:257-268), forward and
+    backward with token gradients, at configs[1]'s batch (64 x 197 tokens) and configs[3]'s
+    (128 x 577).  Token traffic as the kernels are launched: scores and weighted sum read the tokens
+    in the forward pass, both again in the backward pass, and the token gradient is written:
+    5 * N * D * s per sample and modality (3 * N * D * s if every pass read the tokens once per
+    direction)."""
+    from vqa_amd import fusion
+    s = 2 if dtype == torch.bfloat16 else 4
+    out = {}
+    for B, N in ((64, 197), (128, 577)):
+        torch.manual_seed(1)
+        m = fusion.CoAttention(embed_dim=D, num_heads=8, use_pruning=False).to(dev)
+        gen = torch.Generator(device=dev).manual_seed(3)
+        v = torch.randn(B, N, D, device=dev, generator=gen).to(dtype).requires_grad_()
+        q = torch.randn(B, N_TXT, D, device=dev, generator=gen).to(dtype).requires_grad_()
+        vg = torch.randn(B, D, device=dev, generator=gen).to(dtype)
+        qg = torch.randn(B, D, device=dev, generator=gen).to(dtype)
+        cot = torch.randn(B, 2 * D, device=dev, generator=gen)
+
+        def fb():
+            v.grad = None
+            q.grad = None
+            m.zero_grad(set_to_none=True)
+            o = m(v, vg, q, qg)
+            o.backward(cot.to(o.dtype))
+
+        for _ in range(3):
+            fb()
+        torch.cuda.synchronize()
+        launch, graph = "eager", None
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fb()
+            launch = "hipgraph"
+        except Exception as exc:  # capture is an optimisation of the launch path only
+            print(f"[bench] dense leg: graph capture unavailable ({type(exc).__name__}); eager", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+        run = graph.replay if graph is not None else fb
+        for _ in range(3):
+            run()
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        nbytes = 5 * B * (N + N_TXT) * D * s
+        out[f"B{B}_N{N}"] = {"ms_fwd_bwd": round(ms, 5), "launch": launch,
+                             "token_GB/s": round(nbytes / ms / 1e6, 1),
+                             "frac_of_8TBs": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                             "token_bytes": nbytes, "samples/s": round(B / ms * 1e3, 1)}
+        del graph
+    return out
+
+
 def cpu_baseline(sample):
     """The oracle (reference op sequence: MHA weights -> topk -> gather -> masked mean -> cat ->
     mean; per-sample gradients by vmap(grad) -> norms -> clip -> sum -> noise -> scale) on the
@@ -368,6 +429,59 @@ def run_job(args, dev, dtype, rank, world, local_b, logical_b, probe):
     return dt, ("hipgraph" if graphs is not None else "eager"), eager_ms
 
 
+def roofline_obj(probe, local_b, dtype, launch, copy_gbs):
+    """The `roofline` object of the dominant HBM-bound kernel of one measured job."""
+    from vqa_amd import ops
+    s = 2 if dtype == torch.bfloat16 else 4
+    K = ops.keep_count(N_VIS, 1 - KEEP)
+    Kt = ops.keep_count(N_TXT, 1 - KEEP)
+    H = 8
+    traffic = None
+    fused = probe.mean_ms("fused_prune_pool") > 0
+    if fused:
+        # One launch scores, selects and pools both modalities.  Algorithmic bytes per sample and
+        # modality in the two-pass accounting of a fused score+prune (top-k needs every score
+        # before the first row can be pooled, so the tokens are read twice: N*D*s each pass),
+        # plus the folded queries H*D*4, the keep indices K*8 and one pooled row D*s.
+        # `one_pass_bytes` counts the tokens once (what HBM itself must deliver when the second
+        # pass is served on-die).
+        kname = "fused_prune_pool_kernel (scoring + selection + pooled prune/mix, vision + text tokens)"
+        k_ms = probe.mean_ms("fused_prune_pool")
+        per = lambda n, k, passes: passes * n * D * s + H * D * 4 + k * 8 + D * s  # noqa: E731
+        alg_bytes = local_b * (per(N_VIS, K, 2) + per(N_TXT, Kt, 2))
+        one_pass = local_b * (per(N_VIS, K, 1) + per(N_TXT, Kt, 1))
+        pmc_file, pmc_key = "r02_pmc_fused.json", "fused_prune_pool_kernel<16> (both)"
+        pmc_field = "fabric_bytes_per_launch"
+    else:
+        # separate launches (f32 tokens, unsupported widths): the pooled prune+mix launch, every
+        # token row read once, the keep indices read, one pooled row written per modality
+        kname = "gather_mix_pool_multi_kernel (prune+mix, vision + text tokens)"
+        k_ms = probe.mean_ms("gather_mix_pool_multi")
+        alg_bytes = local_b * ((N_VIS * D * s + K * 8 + D * s) + (N_TXT * D * s + Kt * 8 + D * s))
+        one_pass = alg_bytes
+        pmc_file, pmc_key = "r01_pmc_traffic.json", "gather_mix_pool_multi_kernel<true, true, 32>"
+        pmc_field = "hbm_bytes_per_launch"
+    achieved = alg_bytes / k_ms / 1e6 if k_ms > 0 else 0.0
+    try:  # fabric-side bytes per launch from the PMC passes kept under profiles/ (same shape only)
+        with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
+            pmc = json.load(fh)
+        if local_b == 1024 and dtype == torch.bfloat16:
+            traffic = pmc["kernels"][pmc_key][pmc_field]
+    except (OSError, KeyError, ValueError):
+        traffic = None
+    timing = ("stream events around the launch in eagerly launched steps right after the timed region "
+              "(the timed region replays HIP graphs)") if launch == "hipgraph" else \
+             "stream events around the launch inside the timed region"
+    return {"bound": "hbm", "kernel": kname,
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "kernel_ms": round(k_ms, 5), "algorithmic_bytes": alg_bytes,
+            "one_pass_bytes": one_pass,
+            "one_pass_GBs": round(one_pass / k_ms / 1e6, 1) if k_ms > 0 else 0.0,
+            "kernel_timing": timing, "copy_rate_same_run_GBs": round(copy_gbs, 1),
+            "frac_of_copy_rate": round(achieved / copy_gbs, 4) if copy_gbs > 0 else None}
+
+
 def main():
     args = parse()
     if os.environ.get("VQAF_BENCH_WATCHDOG"):  # developer aid: dump all stacks if a rehearsal stalls
@@ -403,48 +517,23 @@ def main():
                           "global_batch": o_logical, "per_gpu_batch": o_local,
                           "ms_per_step": round(o_dt / args.steps * 1e3, 4), "launch": o_launch})
 
+    f32_tier = None
+    if world == 1 and dtype == torch.bfloat16 and not args.no_f32:
+        # the reference's own precision (fp32 tokens, weights and tapes) over the same step, a
+        # shorter run: the fusion goes through the separate f32 launches, the clipped sums through
+        # the f32 matrix cores
+        import copy
+        a32 = copy.copy(args)
+        a32.steps, a32.warmup = min(args.steps, 20), min(args.warmup, 5)
+        p32 = Probe("gather_mix_pool_multi", "fused_prune_pool")
+        ops.PROBE = p32
+        dt32, launch32, _ = run_job(a32, dev, torch.float32, rank, world, local_b, logical_b, p32)
+        ops.PROBE = None
+        f32_tier = {"value": round(logical_b * a32.steps / dt32, 1), "unit": "samples/s",
+                    "ms_per_step": round(dt32 / a32.steps * 1e3, 4), "steps": a32.steps, "launch": launch32,
+                    "roofline": roofline_obj(p32, local_b, torch.float32, launch32, copy_rate_gbs(dev))}
     if rank == 0:
-        s = 2 if dtype == torch.bfloat16 else 4
-        K = ops.keep_count(N_VIS, 1 - KEEP)
-        Kt = ops.keep_count(N_TXT, 1 - KEEP)
-        H = 8
         copy_gbs = copy_rate_gbs(dev)
-        traffic = None
-        fused = probe.mean_ms("fused_prune_pool") > 0
-        if fused:
-            # One launch scores, selects and pools both modalities.  Algorithmic bytes per sample and
-            # modality in the two-pass accounting of a fused score+prune (top-k needs every score
-            # before the first row can be pooled, so the tokens are read twice: N*D*s each pass),
-            # plus the folded queries H*D*4, the keep indices K*8 and one pooled row D*s.
-            # `one_pass_bytes` counts the tokens once (what HBM itself must deliver when the second
-            # pass is served on-die).
-            kname = "fused_prune_pool_kernel (scoring + selection + pooled prune/mix, vision + text tokens)"
-            k_ms = probe.mean_ms("fused_prune_pool")
-            per = lambda n, k, passes: passes * n * D * s + H * D * 4 + k * 8 + D * s  # noqa: E731
-            alg_bytes = local_b * (per(N_VIS, K, 2) + per(N_TXT, Kt, 2))
-            one_pass = local_b * (per(N_VIS, K, 1) + per(N_TXT, Kt, 1))
-            pmc_file, pmc_key = "r02_pmc_fused.json", "fused_prune_pool_kernel<16> (both)"
-            pmc_field = "fabric_bytes_per_launch"
-        else:
-            # separate launches (f32 tokens, unsupported widths): the pooled prune+mix launch, every
-            # token row read once, the keep indices read, one pooled row written per modality
-            kname = "gather_mix_pool_multi_kernel (prune+mix, vision + text tokens)"
-            k_ms = probe.mean_ms("gather_mix_pool_multi")
-            alg_bytes = local_b * ((N_VIS * D * s + K * 8 + D * s) + (N_TXT * D * s + Kt * 8 + D * s))
-            one_pass = alg_bytes
-            pmc_file, pmc_key = "r01_pmc_traffic.json", "gather_mix_pool_multi_kernel<true, true, 32>"
-            pmc_field = "hbm_bytes_per_launch"
-        achieved = alg_bytes / k_ms / 1e6 if k_ms > 0 else 0.0
-        try:  # fabric-side bytes per launch from the PMC passes kept under profiles/ (same shape only)
-            with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
-                pmc = json.load(fh)
-            if local_b == 1024 and args.dtype == "bf16":
-                traffic = pmc["kernels"][pmc_key][pmc_field]
-        except (OSError, KeyError, ValueError):
-            traffic = None
-        timing = ("stream events around the launch in eagerly launched steps right after the timed region "
-                  "(the timed region replays HIP graphs)") if launch == "hipgraph" else \
-                 "stream events around the launch inside the timed region"
         mfma = []
         for name in sorted(probe.pairs):
             if not name.startswith("clipped_sum_linear:"):
@@ -469,20 +558,16 @@ def main():
                                    f"CoAttention pruning keep 0.5, {N_VIS} vision + {N_TXT} text tokens x {D}, "
                                    f"{C} classes; encoders bypassed",
                        "global_batch": logical_b, "per_gpu_batch": local_b, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": kname,
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel_ms": round(k_ms, 5), "algorithmic_bytes": alg_bytes,
-                         "one_pass_bytes": one_pass,
-                         "one_pass_GBs": round(one_pass / k_ms / 1e6, 1) if k_ms > 0 else 0.0,
-                         "kernel_timing": timing, "copy_rate_same_run_GBs": round(copy_gbs, 1),
-                         "frac_of_copy_rate": round(achieved / copy_gbs, 4) if copy_gbs > 0 else None},
+            "roofline": roofline_obj(probe, local_b, dtype, launch, copy_gbs),
             "mfma": mfma,
         }
         if other is not None:
             line[other[0]] = other[1]
+        if f32_tier is not None:
+            line["f32"] = f32_tier
         if not args.no_sweep:
             line["prune_mix_cfg4"] = prune_mix_sweep(dev, dtype)
+            line["dense_branch"] = dense_leg(dev, dtype)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(line), flush=True)
