@@ -493,7 +493,14 @@ def test_fused_select_equals_separate_kernels(dev):
         np.testing.assert_allclose(r["weights"].cpu().numpy(), w_sep.cpu().numpy(), rtol=1e-6, atol=1e-9)
         r2 = ops.select_indices(K, weights=w_sep, want_bottom=True)
         assert torch.equal(r2["top"], top_sep) and torch.equal(r2["bottom"], bot_sep)
-        assert torch.equal(r["bottom"], bot_sep) or N > 500  # identical weights up to the last bit
+        # the one-launch weights differ from vqaf_attn_weights' in the last bit for long rows (other
+        # summation order of the softmax denominator), so its lists are checked against the documented
+        # order of ITS OWN weights: exactly the ranking, top and (reversed) bottom
+        order = fo.stable_order(r["weights"].cpu())
+        assert torch.equal(r["top"].cpu(), order[:, :K])
+        assert torch.equal(r["bottom"].cpu(), order.flip(1)[:, :N - K])
+        if N <= 500:
+            assert torch.equal(r["bottom"], bot_sep)
         if N - K < k_adv:
             continue
         # random swap: same state -> same draws as vqaf_adv_swap_random

@@ -92,8 +92,19 @@ def test_config2_shape_bf16_forward_backward(dev):
     assert fused.dtype == torch.bfloat16
     (fused.float() * cot.to(dev)).sum().backward()
     # keep sets: bf16 scores are f32-accurate here (tokens exact, folded query in two bf16 terms)
-    same = sum(set(a.tolist()) == set(b.tolist()) for a, b in zip(m.v_pruning.last_indices.cpu(), v_idx))
-    assert same >= B - 1
+    # The kernels fold the query into the key projection (x . (Wk^T q)) where the reference projects
+    # every token first ((Wk x) . q): the same number in exact arithmetic, a few ulps apart in f32.
+    # A keep set may therefore differ from the oracle's only by tokens whose weight ties with the
+    # weight at the keep boundary to within that rounding; anything else is a failure.
+    w_or = fo.attention_weights(rb(q_global), rb(v_seq), rb(t2v["in_proj_weight"]), rb(t2v["in_proj_bias"]), 8)
+    w_or = w_or.reshape(B, N)
+    K = v_idx.shape[1]
+    for b_, (a, o) in enumerate(zip(m.v_pruning.last_indices.cpu(), v_idx)):
+        diff = set(a.tolist()) ^ set(o.tolist())
+        if diff:
+            boundary = w_or[b_].sort(descending=True).values[K - 1:K + 1].mean()
+            gaps = (w_or[b_][sorted(diff)] - boundary).abs() / boundary
+            assert len(diff) == 2 and float(gaps.max()) < 1e-4, (b_, sorted(diff), gaps.tolist())
     np.testing.assert_allclose(fused.float().detach().cpu().numpy(), want.detach().numpy(), rtol=1e-2, atol=1e-2)
     gv = vs.grad.float().cpu()
     ok = (m.v_pruning.last_indices.cpu().sort(1).values == v_idx.sort(1).values).all(dim=1)

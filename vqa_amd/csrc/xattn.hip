@@ -106,17 +106,23 @@ softmax_heads_bwd_kernel(const float* __restrict__ p, const float* __restrict__ 
 }
 
 // z[b,h,:] = sum_n c[b,h,n] x[b,n,:].  Workgroup = (sample, 128-column slice); every token row is
-// read once; the H x N coefficients of the sample sit in LDS; fixed-order reduction, no atomics.
+// read once; the sample's coefficients sit in LDS token-major ([n][HP]: a lane fetches the HP
+// weights of its row with 16-byte reads); four rows per lane are in flight; fixed-order reduction,
+// no atomics.
 template <bool BF16, int HP>
 __global__ void __launch_bounds__(XA_THREADS)
 weighted_token_sum_kernel(const void* __restrict__ seq, const float* __restrict__ c, int N, int D,
                           int H, float* __restrict__ z) {
+  constexpr int U = 4;
   extern __shared__ __attribute__((aligned(16))) float xsm[];
-  float* cs = xsm;                       // [H][N]
+  float* cs = xsm;                       // [N][HP]
   float* red = xsm + (size_t)HP * N;     // [XA_ROWS][XA_SLW]
   const int tid = threadIdx.x, b = blockIdx.y, g = tid / XA_LPR, li = tid % XA_LPR;
   const int d0 = blockIdx.x * XA_SLW + li * 8;
-  for (int i = tid; i < H * N; i += XA_THREADS) cs[i] = c[(size_t)b * H * N + i];
+  for (int i = tid; i < HP * N; i += XA_THREADS) {
+    const int h = i / N, n = i % N;
+    cs[n * HP + h] = h < H ? c[((size_t)b * H + h) * N + n] : 0.f;
+  }
   __syncthreads();
   float acc[HP][8];
 #pragma unroll
@@ -124,27 +130,32 @@ weighted_token_sum_kernel(const void* __restrict__ seq, const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[h][i] = 0.f;
   if (d0 < D) {
-    for (int n0 = g; n0 < N; n0 += 2 * XA_ROWS) {
-      float x[2][8];
+    for (int n0 = g; n0 < N; n0 += U * XA_ROWS) {
+      float x[U][8];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < U; ++u)  // rows past the end re-read the last one; their weight is zeroed below
+        load8<BF16>(seq, ((size_t)b * N + min(n0 + u * XA_ROWS, N - 1)) * D + d0, x[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
         const int n = n0 + u * XA_ROWS;
-        if (n < N) load8<BF16>(seq, ((size_t)b * N + n) * D + d0, x[u]);
-        else {
+        const bool in = n < N;
+        const float* cw = cs + (size_t)min(n, N - 1) * HP;
+        float w[HP];
+        if constexpr (HP >= 4) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) x[u][i] = 0.f;
+          for (int h = 0; h < HP; h += 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(cw + h);
+            w[h] = q.x; w[h + 1] = q.y; w[h + 2] = q.z; w[h + 3] = q.w;
+          }
+        } else {
+#pragma unroll
+          for (int h = 0; h < HP; ++h) w[h] = cw[h];
         }
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int n = min(n0 + u * XA_ROWS, N - 1);
 #pragma unroll
         for (int h = 0; h < HP; ++h) {
-          if (h < H) {
-            const float w = cs[h * N + n];
+          const float wh = in ? w[h] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[h][i] = fmaf(w, x[u][i], acc[h][i]);
-          }
+          for (int i = 0; i < 8; ++i) acc[h][i] = fmaf(wh, x[u][i], acc[h][i]);
         }
       }
     }
@@ -168,20 +179,22 @@ weighted_token_sum_kernel(const void* __restrict__ seq, const float* __restrict_
   }
 }
 
-// out[b,n,:] = sum_h ca[b,h,n] va[b,h,:] + cb[b,h,n] vb[b,h,:].  Same geometry; pure write.
+// out[b,n,:] = sum_h ca[b,h,n] va[b,h,:] + cb[b,h,n] vb[b,h,:].  Same geometry; pure write.  The
+// 2*HP coefficients of a row sit together in LDS ([n][2*HP]) and are fetched with 16-byte reads;
+// two rows per lane are computed side by side.
 template <bool BF16, int HP>
 __global__ void __launch_bounds__(XA_THREADS)
 token_outer_kernel(const float* __restrict__ ca, const float* __restrict__ va,
                    const float* __restrict__ cb, const float* __restrict__ vb, int N, int D, int H,
                    void* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float xsm[];
-  float* csa = xsm;
-  float* csb = xsm + (size_t)HP * N;
+  float* cs = xsm;  // [N][2*HP]: a_0..a_{HP-1}, b_0..b_{HP-1}
   const int tid = threadIdx.x, b = blockIdx.y, g = tid / XA_LPR, li = tid % XA_LPR;
   const int d0 = blockIdx.x * XA_SLW + li * 8;
-  for (int i = tid; i < H * N; i += XA_THREADS) {
-    csa[i] = ca[(size_t)b * H * N + i];
-    csb[i] = cb[(size_t)b * H * N + i];
+  for (int i = tid; i < HP * N; i += XA_THREADS) {
+    const int h = i / N, n = i % N;
+    cs[n * 2 * HP + h] = h < H ? ca[((size_t)b * H + h) * N + n] : 0.f;
+    cs[n * 2 * HP + HP + h] = h < H ? cb[((size_t)b * H + h) * N + n] : 0.f;
   }
   __syncthreads();
   if (d0 >= D) return;
@@ -196,19 +209,37 @@ token_outer_kernel(const float* __restrict__ ca, const float* __restrict__ va,
       for (int i = 0; i < 8; ++i) ra[h][i] = rb[h][i] = 0.f;
     }
   }
-  for (int n = g; n < N; n += XA_ROWS) {
-    float o[8];
+  auto row = [&](int n, float (&o)[8]) {
+    const float* cw = cs + (size_t)n * 2 * HP;
+    float w[2 * HP];
+    if constexpr (HP >= 2) {
+#pragma unroll
+      for (int h = 0; h < 2 * HP; h += 4) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(cw + h);
+        w[h] = q.x; w[h + 1] = q.y; w[h + 2] = q.z; w[h + 3] = q.w;
+      }
+    } else {
+      w[0] = cw[0]; w[1] = cw[1];
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = 0.f;
 #pragma unroll
-    for (int h = 0; h < HP; ++h) {
-      if (h < H) {
-        const float wa = csa[h * N + n], wb = csb[h * N + n];
+    for (int h = 0; h < HP; ++h)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = fmaf(wa, ra[h][i], fmaf(wb, rb[h][i], o[i]));
-      }
-    }
-    store8<BF16>(out, ((size_t)b * N + n) * D + d0, o);
+      for (int i = 0; i < 8; ++i) o[i] = fmaf(w[h], ra[h][i], fmaf(w[HP + h], rb[h][i], o[i]));
+  };
+  int n = g;
+  for (; n + XA_ROWS < N; n += 2 * XA_ROWS) {
+    float o0[8], o1[8];
+    row(n, o0);
+    row(n + XA_ROWS, o1);
+    store8<BF16>(out, ((size_t)b * N + n) * D + d0, o0);
+    store8<BF16>(out, ((size_t)b * N + n + XA_ROWS) * D + d0, o1);
+  }
+  if (n < N) {
+    float o0[8];
+    row(n, o0);
+    store8<BF16>(out, ((size_t)b * N + n) * D + d0, o0);
   }
 }
 
