@@ -127,6 +127,10 @@ class RDPAccountant:
     def __init__(self):
         self.history: List[Tuple[float, float, int]] = []
 
+    @classmethod
+    def mechanism(cls) -> str:
+        return "rdp"
+
     def step(self, *, noise_multiplier: float, sample_rate: float) -> None:
         if self.history and self.history[-1][0] == noise_multiplier and self.history[-1][1] == sample_rate:
             nm, sr, n = self.history[-1]
@@ -148,13 +152,23 @@ class RDPAccountant:
 
 
 def get_noise_multiplier(*, target_epsilon: float, target_delta: float, sample_rate: float, steps: int,
-                         epsilon_tolerance: float = 0.01) -> float:
+                         epsilon_tolerance: float = 0.01, accountant: str = "rdp") -> float:
     """Noise multiplier whose epsilon after `steps` steps lands within `epsilon_tolerance` below
     target_epsilon.  The bracketing and bisection follow Opacus 1.4.0's search step for step
     (upper bracket 10 doubled BEFORE its first evaluation, loop on the epsilon gap only, upper
     end returned), so the same target yields the same sigma; parity unpinned (Opacus absent)."""
-    def eps_of(sigma: float) -> float:
-        return rdp_to_epsilon(compute_rdp(sample_rate, sigma, steps), DEFAULT_ALPHAS, target_delta)[0]
+    if accountant == "prv":
+        from .prv import PRVAccountant
+
+        def eps_of(sigma: float) -> float:
+            acc = PRVAccountant()
+            acc.history = [(sigma, sample_rate, steps)]
+            return acc.get_epsilon(target_delta)
+    elif accountant == "rdp":
+        def eps_of(sigma: float) -> float:
+            return rdp_to_epsilon(compute_rdp(sample_rate, sigma, steps), DEFAULT_ALPHAS, target_delta)[0]
+    else:
+        raise ValueError(f"unknown accountant {accountant!r}")
 
     eps_high = math.inf
     sigma_low, sigma_high = 0.0, 10.0

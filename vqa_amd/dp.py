@@ -696,13 +696,18 @@ class DPDataLoader(torch.utils.data.DataLoader):
 class PrivacyEngine:
     """make_private / make_private_with_epsilon / get_epsilon as used at train.py:127-153, 209."""
 
-    def __init__(self, *, accountant: str = "rdp", secure_mode: bool = False):
-        if accountant != "rdp":
-            raise ValueError("only the RDP accountant is implemented")
+    def __init__(self, *, accountant: str = "prv", secure_mode: bool = False):
+        # "prv" is the default of the engine the reference constructs (Opacus 1.4.0, train.py:127)
+        if accountant == "prv":
+            from .prv import PRVAccountant
+            self.accountant = PRVAccountant()
+        elif accountant == "rdp":
+            self.accountant = RDPAccountant()
+        else:
+            raise ValueError(f"unknown accountant {accountant!r}: 'prv' or 'rdp'")
         if secure_mode:
             raise ValueError("secure_mode (cryptographic RNG) is not implemented; the reference "
                              "passes secure_mode=False (train.py:127)")
-        self.accountant = RDPAccountant()
         self.secure_mode = secure_mode
 
     def make_private(self, *, module: nn.Module, optimizer: torch.optim.Optimizer, data_loader,
@@ -747,7 +752,8 @@ class PrivacyEngine:
                                   poisson_sampling: bool = True, **kwargs):
         sample_rate = 1.0 / len(data_loader)
         sigma = get_noise_multiplier(target_epsilon=target_epsilon, target_delta=target_delta,
-                                     sample_rate=sample_rate, steps=int(epochs * len(data_loader)))
+                                     sample_rate=sample_rate, steps=int(epochs * len(data_loader)),
+                                     accountant=self.accountant.mechanism())
         return self.make_private(module=module, optimizer=optimizer, data_loader=data_loader,
                                  noise_multiplier=sigma, max_grad_norm=max_grad_norm,
                                  batch_first=batch_first, loss_reduction=loss_reduction,
