@@ -1,5 +1,5 @@
 """Host restatement of the library's counter RNG (Philox4x32-10 keyed by the 64-bit seed, counter
-words {call lo, call hi, state counter lo, state counter hi}) and of its two noise transforms, so
+words {call lo, call hi, state counter lo, state counter hi}) and of its two token-noise transforms, so
 GPU tests can check in-kernel draws value by value rather than only by their moments."""
 import numpy as np
 
@@ -22,26 +22,29 @@ def philox4x32_10(seed: int, call: np.ndarray, counter: int) -> np.ndarray:
     return np.stack(c, axis=1).astype(np.uint32)
 
 
-def u01(words: np.ndarray) -> np.ndarray:
-    """(r + 0.5) * 2^-32, evaluated as the kernels do it: the word converted to float32 first."""
-    return (words.astype(np.float32) + np.float32(0.5)).astype(np.float64) * 2.0 ** -32
+def u16(half: np.ndarray) -> np.ndarray:
+    """(h + 0.5) / 65536 for a 16-bit half word (exact in float32 and float64 alike)."""
+    return (half.astype(np.float64) + 0.5) / 65536.0
+
+
+def _halves(seed: int, counter: int, n_elements: int):
+    """Token noise: draw e >> 3 serves elements e .. e+7; word i of the draw serves elements 2i, 2i+1
+    through its low (u) and high (v) 16 bits."""
+    calls = np.arange((n_elements + 7) // 8, dtype=np.uint64)
+    w = philox4x32_10(seed, calls, counter)           # (calls, 4)
+    return w & np.uint32(0xFFFF), w >> np.uint32(16)
 
 
 def normal(seed: int, counter: int, n_elements: int) -> np.ndarray:
-    """Exact (float64) Box-Muller values the Gaussian noise kernels approximate: element e takes
-    value e & 3 of draw e >> 2; values 0,1 come from words 0,1 and values 2,3 from words 2,3."""
-    calls = np.arange((n_elements + 3) // 4, dtype=np.uint64)
-    w = philox4x32_10(seed, calls, counter)
-    out = np.empty((len(calls), 4))
-    for a, b, o in ((0, 1, 0), (2, 3, 2)):
-        u, v = u01(w[:, a]), u01(w[:, b])
-        r = np.sqrt(-2.0 * np.log(u))
-        out[:, o] = r * np.cos(2 * np.pi * v)
-        out[:, o + 1] = r * np.sin(2 * np.pi * v)
+    """Exact (float64) Box-Muller values the Gaussian token-noise kernels approximate."""
+    lo, hi = _halves(seed, counter, n_elements)
+    u, v = u16(lo), u16(hi)
+    r = np.sqrt(-2.0 * np.log(u))
+    out = np.stack([r * np.cos(2 * np.pi * v), r * np.sin(2 * np.pi * v)], axis=2)  # (calls, 4, 2)
     return out.reshape(-1)[:n_elements]
 
 
 def uniform(seed: int, counter: int, n_elements: int) -> np.ndarray:
-    calls = np.arange((n_elements + 3) // 4, dtype=np.uint64)
-    w = philox4x32_10(seed, calls, counter)
-    return (2.0 * u01(w) - 1.0).reshape(-1)[:n_elements]
+    lo, hi = _halves(seed, counter, n_elements)
+    out = np.stack([2.0 * u16(lo) - 1.0, 2.0 * u16(hi) - 1.0], axis=2)
+    return out.reshape(-1)[:n_elements]

@@ -348,9 +348,10 @@ def test_in_kernel_noise_statistics(dev):
 
 def test_in_kernel_noise_values_vs_host_generator(dev):
     """Every in-kernel draw against the host restatement of the generator: the keep slot (b, j),
-    column d takes element ((b K + j) D + d) of stream (seed, counter).  The Gaussian flavour goes
-    through the hardware log / sqrt / sin / cos: absolute error below 2e-5 of a standard deviation
-    out to the largest value a 32-bit uniform can produce (6.66 sigma)."""
+    column d takes element ((b K + j) D + d) of stream (seed, counter); one generator call serves
+    eight elements (two 16-bit uniforms per word).  The Gaussian flavour goes through the hardware
+    log / sqrt / sin / cos: absolute error below 2e-5 of a standard deviation out to the largest
+    value a 16-bit uniform can produce (4.85 sigma)."""
     import philox_np
     from vqa_amd import ops
     B, N, D, K = 6, 40, 256, 17

@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 B, D, H = int(os.environ.get("B", 1024)), 512, 8
 NV, NQ = int(os.environ.get("NV", 197)), 30
 nbuf = 4
+NOISE = os.environ.get("NOISE")  # gaussian | uniform | unset
 gen = torch.Generator(device=dev).manual_seed(1)
 vs = [torch.randn(B, NV, D, device=dev, generator=gen).bfloat16() for _ in range(nbuf)]
 qs = [torch.randn(B, NQ, D, device=dev, generator=gen).bfloat16() for _ in range(nbuf)]
@@ -22,8 +23,11 @@ rng = ops.PhiloxState(dev, seed=3)
 
 def spec(seq, N):
     k = ops.keep_count(N, 0.5)
-    return dict(q=qg, seq=seq, in_proj_weight=w, in_proj_bias=bias, num_heads=H, k=k, k_adv=ops.adv_count(k, 0.2),
-                alpha=0.05)
+    d = dict(q=qg, seq=seq, in_proj_weight=w, in_proj_bias=bias, num_heads=H, k=k, k_adv=ops.adv_count(k, 0.2),
+             alpha=0.05)
+    if NOISE and N == NV:  # the reference's default: noise on the vision tokens only (utils/fusion.py:211,221)
+        d.update(noise_type=NOISE, noise_scale=0.01)
+    return d
 
 
 class P:

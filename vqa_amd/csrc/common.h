@@ -180,23 +180,54 @@ __device__ __forceinline__ void vqaf_normal4(unsigned long long seed, unsigned l
   vqaf_box_muller(r.x, r.y, z[0], z[1]);
   vqaf_box_muller(r.z, r.w, z[2], z[3]);
 }
-// The token-noise flavour of the same draw (utils/fusion.py:96-116: a regulariser added to kept
-// tokens, not the privacy mechanism): the same Philox words through the hardware transcendentals --
-// v_log_f32, v_sqrt_f32 and v_sin/v_cos_f32, whose argument is in revolutions, so the uniform goes
-// in unscaled.  About 12 instructions per pair instead of ~80; the absolute error of a value is
-// below 1e-5 (the library's moment and tail tests hold for either flavour).  The DP noise keeps
-// vqaf_normal4.
-__device__ __forceinline__ void vqaf_box_muller_fast(unsigned int a, unsigned int b, float& n0, float& n1) {
-  const float u = vqaf_u01(a), v = vqaf_u01(b);
-  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));  // -2 ln u = -2 ln2 log2 u
-  n0 = r * __builtin_amdgcn_cosf(v);
-  n1 = r * __builtin_amdgcn_sinf(v);
-}
-__device__ __forceinline__ void vqaf_normal4_fast(unsigned long long seed, unsigned long long counter,
-                                                  unsigned long long call, float (&z)[4]) {
+// Token noise (utils/fusion.py:96-116: a regulariser added to kept tokens, not the privacy
+// mechanism; the DP noise keeps vqaf_normal4).  One Philox call serves EIGHT consecutive elements:
+// each 32-bit word is split into two 16-bit uniforms ((h + 0.5) / 65536) that give one Box-Muller
+// pair through the hardware transcendentals (v_log_f32, v_sqrt_f32, v_sin/v_cos_f32, whose argument
+// is in revolutions, so the angle goes in unscaled), or two U(-1,1) values.  Word i of the call
+// serves elements 2i and 2i+1.  16 bits per uniform are far finer than the bf16 tokens the noise
+// is added to and cap |z| at 4.85 sigma; the generator, not the transform, is what the noise costs
+// (twenty 32x32-bit products per call), so halving the calls halves it.
+__device__ __forceinline__ void vqaf_token_normal8(unsigned long long seed, unsigned long long counter,
+                                                   unsigned long long call, float (&z)[8]) {
   const Philox4 r = philox4x32_10(seed, call, counter);
-  vqaf_box_muller_fast(r.x, r.y, z[0], z[1]);
-  vqaf_box_muller_fast(r.z, r.w, z[2], z[3]);
+  const unsigned int w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float u = ((float)(w[i] & 0xffffu) + 0.5f) * (1.0f / 65536.0f);
+    const float v = ((float)(w[i] >> 16) + 0.5f) * (1.0f / 65536.0f);
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));  // -2 ln u
+    z[2 * i] = rad * __builtin_amdgcn_cosf(v);
+    z[2 * i + 1] = rad * __builtin_amdgcn_sinf(v);
+  }
+}
+__device__ __forceinline__ void vqaf_token_uniform8(unsigned long long seed, unsigned long long counter,
+                                                    unsigned long long call, float (&z)[8]) {
+  const Philox4 r = philox4x32_10(seed, call, counter);
+  const unsigned int w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    z[2 * i] = ((float)(w[i] & 0xffffu) + 0.5f) * (2.0f / 65536.0f) - 1.0f;
+    z[2 * i + 1] = ((float)(w[i] >> 16) + 0.5f) * (2.0f / 65536.0f) - 1.0f;
+  }
+}
+// Adds the noise of elements [e, e + 8) (e a multiple of 8) to v: injected values, or draw e / 8 of
+// stream (seed, counter).
+__device__ __forceinline__ void vqaf_token_noise8(float (&v)[8], const float* noise, int noise_kind,
+                                                  float noise_scale, unsigned long long seed,
+                                                  unsigned long long counter, size_t e) {
+  if (noise != nullptr) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(noise + e);
+    const f32x4 a = p[0], b = p[1];
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+    v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  } else if (noise_kind != VQAF_NOISE_NONE) {
+    float z[8];
+    if (noise_kind == VQAF_NOISE_GAUSSIAN) vqaf_token_normal8(seed, counter, e >> 3, z);
+    else vqaf_token_uniform8(seed, counter, e >> 3, z);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaf(noise_scale, z[i], v[i]);
+  }
 }
 // Same draw as four U(-1,1) values.
 __device__ __forceinline__ void vqaf_uniform4(unsigned long long seed, unsigned long long counter,

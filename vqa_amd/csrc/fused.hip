@@ -246,22 +246,8 @@ fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, const uint64_t* __rest
   } else if (M.noise_kind != VQAF_NOISE_NONE) {
     const unsigned long long nseed = M.noise_rng[0];
     const unsigned long long ncounter = M.noise_rng[1] + (unsigned long long)M.noise_ctr_off;
-    for (int j = g; j < K; j += ROWS) {
-      const size_t e = ((size_t)b * K + j) * D + d0;
-      float z0[4], z1[4];
-      if (M.noise_kind == VQAF_NOISE_GAUSSIAN) {
-        vqaf_normal4_fast(nseed, ncounter, e >> 2, z0);
-        vqaf_normal4_fast(nseed, ncounter, (e >> 2) + 1, z1);
-      } else {
-        vqaf_uniform4(nseed, ncounter, e >> 2, z0);
-        vqaf_uniform4(nseed, ncounter, (e >> 2) + 1, z1);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acck[i] += M.noise_scale * z0[i];
-        acck[4 + i] += M.noise_scale * z1[i];
-      }
-    }
+    for (int j = g; j < K; j += ROWS)
+      vqaf_token_noise8(acck, nullptr, M.noise_kind, M.noise_scale, nseed, ncounter, ((size_t)b * K + j) * D + d0);
   }
   // fixed-order fold of the ROWS lane groups; `red` overlays the pass-1 operand (all waves are
   // past pass 1: several barriers ago)

@@ -68,26 +68,7 @@ __host__ __device__ inline PmCarve pm_carve(int N, int K, int NP, int k_adv) {
 
 __device__ __forceinline__ void pm_noise8(float (&v)[8], const float* noise, int noise_kind, float noise_scale,
                                           unsigned long long seed, unsigned long long counter, size_t e) {
-  if (noise != nullptr) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(noise + e);
-    const f32x4 a = p[0], b = p[1];
-    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-    v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-  } else if (noise_kind != VQAF_NOISE_NONE) {
-    float z0[4], z1[4];
-    if (noise_kind == VQAF_NOISE_GAUSSIAN) {
-      vqaf_normal4_fast(seed, counter, e >> 2, z0);
-      vqaf_normal4_fast(seed, counter, (e >> 2) + 1, z1);
-    } else {
-      vqaf_uniform4(seed, counter, e >> 2, z0);
-      vqaf_uniform4(seed, counter, (e >> 2) + 1, z1);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[i] += noise_scale * z0[i];
-      v[4 + i] += noise_scale * z1[i];
-    }
-  }
+  vqaf_token_noise8(v, noise, noise_kind, noise_scale, seed, counter, e);
 }
 
 template <bool BF16, bool BF16_OUT>
