@@ -309,9 +309,13 @@ typedef struct vqaf_fused_mod {
                                same rng state and the caller advances it once for them (what the
                                separate launches see: select, advance, pool), else 0 */
 } vqaf_fused_mod;
+/* rng_advance > 0: `sel_rng_state` is a FOUR-word state {seed, counter, ticket, reserved} (ticket zero)
+ * and the last workgroup of the launch adds rng_advance to its counter, which replaces the
+ * vqaf_rng_advance launch(es) that would follow; every noise_rng_state must then be the same state.
+ * rng_advance == 0: two words suffice and the caller advances. */
 int vqaf_fused_prune_pool_multi(const vqaf_fused_mod* mods_host, int n_mod, int B, int D, int H, int dtype,
-                                const uint64_t* sel_rng_state, void* out, int ld_out, int out_dtype,
-                                vqaf_stream_t stream);
+                                uint64_t* sel_rng_state, int rng_advance, void* out, int ld_out,
+                                int out_dtype, vqaf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense single-query cross-attention (non-pruning branch): the attention OUTPUT of
@@ -431,29 +435,43 @@ int vqaf_noise_scale(const float* S, const float* noise, const uint64_t* rng_sta
  * decay, bias-corrected moments), fused over flat f32 buckets of n elements:
  *   g = (S + noise_std z) * scale;  p *= 1 - lr*wd;  m += (1-b1)(g - m);  v = b2 v + (1-b2) g^2;
  *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),   t = step[1] + 1.
- * `step` = two uint64 in device memory {unused, updates applied so far} (advance it with
- * vqaf_rng_advance after the call).  shadow_bf16 (n bf16, may be NULL) receives the updated
+ * `step` = uint64 words in device memory {unused, updates applied so far}: with step_advance == 0
+ * two words, advanced by the caller (vqaf_rng_advance) after the call; with step_advance > 0 FOUR
+ * words {unused, updates, ticket, reserved} (ticket zero) and the last workgroup adds step_advance
+ * to the count itself.  `step` may double as rng_state.  shadow_bf16 (n bf16, may be NULL) receives the updated
  * parameters rounded to bf16; grad_out (n f32, may be NULL, may alias S) receives g.
  * This is the step train.py:130-141 configures: AdamW on the classifier wrapped by the DP
  * optimizer (utils/src.py:104). */
 int vqaf_dp_adamw(const float* S, const float* noise, const uint64_t* rng_state, float noise_std,
                   float scale, float* param, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                   float* grad_out, size_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, const uint64_t* step, vqaf_stream_t stream);
+                  float weight_decay, uint64_t* step, int step_advance, vqaf_stream_t stream);
+
+/* Zeroes up to 8 float ranges (pointer, element count) in one launch: the accumulators of the
+ * clipped sums that add atomically (then called with accumulate = 1), instead of one memset each. */
+int vqaf_zero_multi(float* const* ptrs_host, const size_t* counts_host, int n_ranges, vqaf_stream_t stream);
 
 /* GroupNorm (+ optional ReLU) on (B,C) input, as the classifier holds after
  * ModuleValidator.fix swaps BatchNorm1d for GroupNorm(min(32,C), C) (train.py:124;
- * model/model.py:56-61).  Saves xhat (B,C) for the backward and the ghost norms. */
+ * model/model.py:56-61).  Saves xhat (B,C) for the backward and the ghost norms.
+ * dropout_p > 0 (needs relu): the nn.Dropout that follows the ReLU (model/model.py:57-58) applied to
+ * y in the same pass -- inverted dropout; the keep decision of element e is drawn from stream
+ * (dropout_seed, dropout_counter[1]).  dropout_counter is any {unused, count} pair in device memory
+ * that changes between training steps (the step count vqaf_dp_adamw keeps serves: no launch is spent
+ * on a counter of its own, and a replayed HIP graph draws fresh masks); dropout_seed tells apart
+ * the call sites within one step. */
 int vqaf_groupnorm_fwd(const void* x, const void* gamma, const void* beta, int B, int C,
                        int groups, float eps, int relu, int dtype, void* y, void* xhat,
-                       float* rstd, vqaf_stream_t stream);
+                       float* rstd, float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_counter,
+                       vqaf_stream_t stream);
 
 /* Backward of the above w.r.t. x only (parameter gradients come from the clipped sums).
  * y is the forward output (for the ReLU mask); writes g_pre (B,C), the gradient at the
  * GroupNorm output before the affine (what the ghost norms and clipped sums consume),
- * and grad_x (B,C). */
+ * and grad_x (B,C).  out_scale = 1/(1 - dropout_p) when the forward applied dropout (y > 0 is then both
+ * the ReLU gate and the keep mask), 1 otherwise. */
 int vqaf_groupnorm_bwd(const void* grad_y, const void* y, const void* xhat, const float* rstd,
-                       const void* gamma, int B, int C, int groups, int relu, int dtype,
+                       const void* gamma, int B, int C, int groups, int relu, float out_scale, int dtype,
                        void* g_pre, void* grad_x, vqaf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

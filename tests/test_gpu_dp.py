@@ -145,7 +145,7 @@ def test_dp_kernels_bf16_same_inputs(dev):
     rstd = torch.empty(B, groups, device=dev)
     xd, gamd, betd = x.to(dev), gam.to(dev), bet.to(dev)  # keep the device copies alive
     check(lib.vqaf_groupnorm_fwd(ptr(xd), ptr(gamd), ptr(betd), B, C, groups, 1e-5, 1,
-                                 BF16, ptr(y), ptr(xh), ptr(rstd), st), "gn")
+                                 BF16, ptr(y), ptr(xh), ptr(rstd), 0.0, 0, None, st), "gn")
     want_y = torch.relu(torch.nn.functional.group_norm(x.float(), groups, gam.float(), bet.float(), 1e-5))
     np.testing.assert_allclose(y.float().cpu().numpy(), want_y.numpy(), rtol=1e-2, atol=1e-2)
 
@@ -570,3 +570,110 @@ def test_dp_step_bf16_batch_1024_bounds_and_direction(dev):
     assert float(clipped_norm.max()) > 0.99 * max_norm  # the margin is small
     frac_clipped = float((opt.last_clip < 0.999).double().mean())
     assert 0.3 < frac_clipped < 0.7, frac_clipped
+
+
+# ------------------------------------------------------------------ fused small launches
+def test_groupnorm_relu_dropout_in_one_launch(dev):
+    """GroupNorm -> ReLU -> Dropout(p) as the classifier holds them (model/model.py:56-58) in the
+    GroupNorm launch: the output equals relu(group_norm(x)) scaled by 1/(1-p) where kept and is
+    exactly zero where dropped, the keep rate is p-consistent, the mask changes from call to call
+    and repeats for the same generator state; the backward equals autograd's through the same mask."""
+    from vqa_amd import dp, ops
+    B, C, p = 256, 2048, 0.3
+    torch.manual_seed(3)
+    seq = nn.Sequential(nn.Linear(64, C), nn.GroupNorm(32, C), nn.ReLU(), nn.Dropout(p), nn.Linear(C, 8)).to(dev)
+    gsm = dp.GradSampleModule(seq)
+    gsm.train()
+    x = gi.normal(5, B, 64).to(dev)
+    h = seq[0](x).detach().requires_grad_()
+    tape_mod = dp.GradSampleModule(nn.Sequential(seq[1], seq[2], seq[3]))
+    tape_mod.train()
+    y1 = tape_mod(h)
+    with torch.no_grad():
+        ref = torch.relu(torch.nn.functional.group_norm(h.detach(), 32, seq[1].weight, seq[1].bias, seq[1].eps))
+    kept = y1.detach() != 0
+    live = ref > 0
+    assert bool((kept <= live).all())
+    np.testing.assert_allclose(y1[kept].detach().cpu().numpy(), (ref[kept] / (1 - p)).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    rate = float(kept.sum()) / float(live.sum())
+    n_live = float(live.sum())
+    assert abs(rate - (1 - p)) < 5 * (p * (1 - p) / n_live) ** 0.5 + 2e-5   # 16-bit threshold granularity
+    assert int(tape_mod.dropout_rng.state[1].item()) == 1 and int(tape_mod.dropout_rng.state[2].item()) == 0
+    # backward through the same mask
+    cot = gi.normal(7, B, C).to(dev)
+    (y1 * cot).sum().backward()
+    h2 = h.detach().clone().requires_grad_()
+    mask = kept.float() / (1 - p)
+    (torch.relu(torch.nn.functional.group_norm(h2, 32, seq[1].weight.detach(), seq[1].bias.detach(), seq[1].eps))
+     * mask * cot).sum().backward()
+    np.testing.assert_allclose(h.grad.cpu().numpy(), h2.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    # a second call draws another mask; the same state draws the same one
+    y2 = tape_mod(h.detach()).detach()
+    assert not torch.equal(y2 != 0, kept)
+    tape_mod.dropout_rng.state[1] = 0
+    tape_mod._drop_calls = 0
+    y3 = tape_mod(h.detach()).detach()
+    assert torch.equal(y3, y1.detach())
+    # keyed on an optimizer's step count instead (no counter launch of its own): the same (call site,
+    # step) gives the same mask, another step or another call site another one
+    own = tape_mod.dropout_rng.state.clone()
+    tape_mod.step_counter = torch.tensor([0, 5, 0, 0], dtype=torch.int64, device=dev)
+    tape_mod._drop_calls = 0
+    a = tape_mod(h.detach()).detach()
+    b = tape_mod(h.detach()).detach()          # second call site of the same step
+    tape_mod._drop_calls = 0
+    c = tape_mod(h.detach()).detach()
+    tape_mod.step_counter[1] = 6
+    tape_mod._drop_calls = 0
+    d = tape_mod(h.detach()).detach()
+    assert torch.equal(a, c) and not torch.equal(a != 0, b != 0) and not torch.equal(a != 0, d != 0)
+    assert torch.equal(tape_mod.dropout_rng.state, own)
+    tape_mod.step_counter = None
+    # eval mode: no dropout, no draw
+    tape_mod.eval()
+    before = int(tape_mod.dropout_rng.state[1].item())
+    np.testing.assert_allclose(tape_mod(h.detach()).detach().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert int(tape_mod.dropout_rng.state[1].item()) == before
+
+
+def test_in_kernel_counter_bumps_and_zero_multi(dev):
+    """The generator counters that kernels bump themselves (last workgroup out) end where the
+    separate vqaf_rng_advance launches would have left them, and the ticket word is back at zero;
+    vqaf_zero_multi clears exactly the ranges it is given."""
+    import ctypes
+    from vqa_amd import ops
+    from vqa_amd._lib import check, load, ptr, stream_ptr
+    lib, st = load(), stream_ptr(dev)
+    # fused AdamW counting its own steps: many workgroups, several launches
+    n = 1 << 20
+    S = torch.randn(n, device=dev)
+    P, M, V = torch.randn(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step = ops.PhiloxState(dev, seed=5).state
+    for k in range(3):
+        check(lib.vqaf_dp_adamw(ptr(S), None, ptr(step), 1.0, 1.0 / 64, ptr(P), ptr(M), ptr(V), None, None, n,
+                                1e-3, 0.9, 0.999, 1e-8, 0.01, ptr(step), 1, st), "adamw")
+        assert step[1:3].tolist() == [k + 1, 0]
+    # the same three updates with the caller advancing: identical parameters (same draws, same step counts)
+    P2, M2, V2 = torch.randn(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    torch.manual_seed(0)
+    P2.copy_(P * 0 + 1.0)
+    P3, M3, V3 = P2.clone(), M2.clone(), V2.clone()
+    sa, sb = ops.PhiloxState(dev, seed=9).state, ops.PhiloxState(dev, seed=9).state
+    for _ in range(3):
+        check(lib.vqaf_dp_adamw(ptr(S), None, ptr(sa), 1.0, 1.0 / 64, ptr(P2), ptr(M2), ptr(V2), None, None, n,
+                                1e-3, 0.9, 0.999, 1e-8, 0.01, ptr(sa), 1, st), "adamw")
+        check(lib.vqaf_dp_adamw(ptr(S), None, ptr(sb), 1.0, 1.0 / 64, ptr(P3), ptr(M3), ptr(V3), None, None, n,
+                                1e-3, 0.9, 0.999, 1e-8, 0.01, ptr(sb), 0, st), "adamw")
+        check(lib.vqaf_rng_advance(ptr(sb), 1, st), "adv")
+    assert torch.equal(P2, P3) and torch.equal(M2, M3) and torch.equal(V2, V3) and torch.equal(sa, sb)
+    # zero_multi
+    buf = torch.ones(10000, device=dev)
+    ranges = [buf[3:10], buf[100:1124], buf[5000:5001], buf[6001:9000]]
+    zp = (ctypes.c_void_p * 4)(*[ptr(r) for r in ranges])
+    zn = (ctypes.c_size_t * 4)(*[r.numel() for r in ranges])
+    check(lib.vqaf_zero_multi(zp, zn, 4, st), "zero")
+    want = torch.ones(10000)
+    for lo, hi in ((3, 10), (100, 1124), (5000, 5001), (6001, 9000)):
+        want[lo:hi] = 0
+    assert torch.equal(buf.cpu(), want)
+    assert lib.vqaf_zero_multi(zp, zn, 9, st) != 0

@@ -100,7 +100,7 @@ SIGNATURES = {
     "vqaf_prune_mix_supported": (c_int, [c_int, c_int, c_int]),
     "vqaf_prune_mix": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_uint64, _P, c_int,
                                c_float, _P, c_int, c_float, c_int, _P, _P, _P]),
-    "vqaf_fused_prune_pool_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P]),
+    "vqaf_fused_prune_pool_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P]),
     "vqaf_gemm_f32": (c_int, [_P, c_int, c_long, c_long, c_long, _P, c_int, c_long, c_long, c_long,
                               _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
                               c_float, c_int, _P]),
@@ -116,10 +116,11 @@ SIGNATURES = {
     "vqaf_clipped_sum_affine": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_noise_scale": (c_int, [_P, _P, _P, c_float, c_float, c_size_t, _P, _P]),
     "vqaf_dp_adamw": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, c_float, c_float,
-                              c_float, c_float, c_float, _P, _P]),
+                              c_float, c_float, c_float, _P, c_int, _P]),
+    "vqaf_zero_multi": (c_int, [_P, _P, c_int, _P]),
     "vqaf_groupnorm_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int, _P, _P,
-                                   _P, _P]),
-    "vqaf_groupnorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P,
+                                   _P, c_float, ctypes.c_uint64, _P, _P]),
+    "vqaf_groupnorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P,
                                    _P]),
     "vqaf_ce_conf": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P]),
 }

@@ -180,6 +180,24 @@ __device__ __forceinline__ void vqaf_normal4(unsigned long long seed, unsigned l
   vqaf_box_muller(r.x, r.y, z[0], z[1]);
   vqaf_box_muller(r.z, r.w, z[2], z[3]);
 }
+// In-kernel counter bump for a FOUR-word generator state {seed, counter, ticket, reserved}: every
+// workgroup calls this once, after its last read of the state; the last one to arrive adds `delta`
+// to the counter and clears the ticket (which starts at zero and is zero between launches).  Saves the
+// separate one-thread launch that would otherwise follow every kernel that draws random numbers.
+// All threads of the workgroup must call it (it contains a barrier).
+__device__ __forceinline__ void vqaf_rng_bump_by_last_workgroup(uint64_t* state, unsigned long long delta,
+                                                                 unsigned int total_workgroups) {
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    __threadfence();
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(state + 2);
+    if (atomicAdd(ticket, 1u) == total_workgroups - 1u) {
+      state[1] += delta;
+      atomicExch(ticket, 0u);
+    }
+  }
+}
+
 // Token noise (utils/fusion.py:96-116: a regulariser added to kept tokens, not the privacy
 // mechanism; the DP noise keeps vqaf_normal4).  One Philox call serves EIGHT consecutive elements:
 // each 32-bit word is split into two 16-bit uniforms ((h + 0.5) / 65536) that give one Box-Muller

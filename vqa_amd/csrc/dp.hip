@@ -577,10 +577,10 @@ noise_scale_kernel(const float* __restrict__ S, const float* __restrict__ noise,
 // number of updates already applied (device memory, so a replayed HIP graph keeps counting).
 __global__ void __launch_bounds__(DP_THREADS)
 dp_adamw_kernel(const float* __restrict__ S, const float* __restrict__ noise,
-                const uint64_t* __restrict__ rng_state, float noise_std, float scale,
+                const uint64_t* rng_state, float noise_std, float scale,
                 float* __restrict__ param, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                 bf16_t* __restrict__ shadow, float* __restrict__ grad_out, size_t n, float lr, float beta1,
-                float beta2, float eps, float weight_decay, const uint64_t* __restrict__ step) {
+                float beta2, float eps, float weight_decay, uint64_t* step, int advance) {
   unsigned long long seed = 0, counter = 0;
   const bool draw = (noise == nullptr) && (noise_std != 0.f);
   if (draw) {
@@ -654,6 +654,8 @@ dp_adamw_kernel(const float* __restrict__ S, const float* __restrict__ noise,
       }
     }
   }
+  // `step` (which may also be the noise state) was read before the loop by every thread
+  if (advance != 0) vqaf_rng_bump_by_last_workgroup(step, (unsigned long long)advance, gridDim.x);
 }
 
 // GroupNorm on (B,C): one workgroup per sample, a lane owns 8 consecutive channels, a group of
@@ -662,9 +664,16 @@ template <bool BF16>
 __global__ void __launch_bounds__(DP_THREADS)
 groupnorm_fwd_kernel(const void* __restrict__ x, const void* __restrict__ gamma,
                      const void* __restrict__ beta, int C, int groups, float eps, int relu,
-                     void* __restrict__ y, void* __restrict__ xhat, float* __restrict__ rstd) {
+                     void* __restrict__ y, void* __restrict__ xhat, float* __restrict__ rstd,
+                     float drop_p, unsigned long long drop_seed, const uint64_t* __restrict__ drop_counter) {
   const int b = blockIdx.x;
   const int gs = C / groups, lpg = gs >= 8 ? gs / 8 : 1;
+  // inverted dropout on the output (nn.Dropout after the ReLU, model/model.py:57-58): element e is
+  // kept when its 16-bit uniform (two per generator word, eight elements per call) is >= p
+  const bool drop = drop_counter != nullptr && drop_p > 0.f;
+  const unsigned long long dseed = drop_seed, dcounter = drop ? drop_counter[1] : 0ull;
+  const unsigned int drop_thr = (unsigned int)(drop_p * 65536.0f);
+  const float keep_scale = drop ? 1.0f / (1.0f - drop_p) : 1.0f;
   for (int c0 = threadIdx.x * 8; c0 < C; c0 += DP_THREADS * 8) {
     float v[8], rsv[8];
     load8<BF16>(x, (size_t)b * C + c0, v);
@@ -724,6 +733,15 @@ groupnorm_fwd_kernel(const void* __restrict__ x, const void* __restrict__ gamma,
       yo[i] = fmaf(v[i], ga[i], be[i]);
       if (relu) yo[i] = fmaxf(yo[i], 0.f);
     }
+    if (drop) {
+      const Philox4 r = philox4x32_10(dseed, ((size_t)b * C + c0) >> 3, dcounter);
+      const unsigned int w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        yo[2 * i] = (w[i] & 0xffffu) >= drop_thr ? yo[2 * i] * keep_scale : 0.f;
+        yo[2 * i + 1] = (w[i] >> 16) >= drop_thr ? yo[2 * i + 1] * keep_scale : 0.f;
+      }
+    }
     store8<BF16>(y, (size_t)b * C + c0, yo);
     store8<BF16>(xhat, (size_t)b * C + c0, v);
   }
@@ -733,7 +751,7 @@ template <bool BF16>
 __global__ void __launch_bounds__(DP_THREADS)
 groupnorm_bwd_kernel(const void* __restrict__ grad_y, const void* __restrict__ y,
                      const void* __restrict__ xhat, const float* __restrict__ rstd,
-                     const void* __restrict__ gamma, int C, int groups, int relu,
+                     const void* __restrict__ gamma, int C, int groups, int relu, float out_scale,
                      void* __restrict__ g_pre, void* __restrict__ grad_x) {
   const int b = blockIdx.x;
   const int gs = C / groups, lpg = gs >= 8 ? gs / 8 : 1;
@@ -745,7 +763,9 @@ groupnorm_bwd_kernel(const void* __restrict__ grad_y, const void* __restrict__ y
     if (relu) {
       load8<BF16>(y, (size_t)b * C + c0, yo);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) gy[i] = yo[i] > 0.f ? gy[i] : 0.f;
+      // y > 0 is the ReLU gate AND the dropout keep mask (dropped outputs are exactly zero);
+      // out_scale = 1 / (1 - p) of the inverted dropout, 1 without it
+      for (int i = 0; i < 8; ++i) gy[i] = yo[i] > 0.f ? gy[i] * out_scale : 0.f;
     }
     store8<BF16>(g_pre, (size_t)b * C + c0, gy);
     float dx[8];
@@ -1003,6 +1023,50 @@ extern "C" int vqaf_clipped_sum_affine(const void* xhat, const void* g, const fl
   VQAF_LAUNCH_CHECK();
 }
 
+namespace {
+constexpr int ZM_MAX = 8;
+struct ZeroRanges {
+  float* p[ZM_MAX];
+  unsigned long long n[ZM_MAX];  // elements
+  int count;
+};
+// blockIdx.y picks the range; 16-byte stores where the range allows.
+__global__ void __launch_bounds__(DP_THREADS) zero_multi_kernel(ZeroRanges R) {
+  float* p = nullptr;
+  unsigned long long n = 0;
+#pragma unroll
+  for (int i = 0; i < ZM_MAX; ++i)
+    if (i == (int)blockIdx.y) { p = R.p[i]; n = R.n[i]; }
+  const bool vec = (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+  const unsigned long long n4 = vec ? n / 4 : 0;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (unsigned long long i = 4 * n4 + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    p[i] = 0.f;
+}
+}  // namespace
+
+extern "C" int vqaf_zero_multi(float* const* ptrs_host, const size_t* counts_host, int n_ranges,
+                               vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(ptrs_host && counts_host, VQAF_E_NULL);
+  VQAF_REQUIRE(n_ranges > 0 && n_ranges <= ZM_MAX, VQAF_E_SHAPE);
+  ZeroRanges R = {};
+  size_t longest = 0;
+  for (int i = 0; i < n_ranges; ++i) {
+    VQAF_REQUIRE(ptrs_host[i] != nullptr, VQAF_E_NULL);
+    R.p[i] = ptrs_host[i];
+    R.n[i] = counts_host[i];
+    longest = counts_host[i] > longest ? counts_host[i] : longest;
+  }
+  R.count = n_ranges;
+  size_t blocks = (longest / 4 + DP_THREADS - 1) / DP_THREADS;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(zero_multi_kernel, dim3((unsigned)blocks, n_ranges), dim3(DP_THREADS), 0, (hipStream_t)stream, R);
+  VQAF_LAUNCH_CHECK();
+}
+
 extern "C" int vqaf_noise_scale(const float* S, const float* noise, const uint64_t* rng_state,
                                 float noise_std, float scale, size_t n, float* grad,
                                 vqaf_stream_t stream) {
@@ -1024,10 +1088,10 @@ extern "C" int vqaf_dp_adamw(const float* S, const float* noise, const uint64_t*
                              float noise_std, float scale, float* param, float* exp_avg,
                              float* exp_avg_sq, void* shadow_bf16, float* grad_out, size_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay,
-                             const uint64_t* step, vqaf_stream_t stream) {
+                             uint64_t* step, int step_advance, vqaf_stream_t stream) {
   VQAF_ENTRY();
   VQAF_REQUIRE(S && param && exp_avg && exp_avg_sq && step, VQAF_E_NULL);
-  VQAF_REQUIRE(n > 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(n > 0 && step_advance >= 0, VQAF_E_SHAPE);
   VQAF_REQUIRE(noise != nullptr || noise_std == 0.f || rng_state != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_aligned16(S) && vqaf_aligned16(param) && vqaf_aligned16(exp_avg) &&
                    vqaf_aligned16(exp_avg_sq) && (noise == nullptr || vqaf_aligned16(noise)) &&
@@ -1040,37 +1104,42 @@ extern "C" int vqaf_dp_adamw(const float* S, const float* noise, const uint64_t*
   hipLaunchKernelGGL(dp_adamw_kernel, dim3((unsigned)blocks), dim3(DP_THREADS), 0, (hipStream_t)stream,
                      S, noise, rng_state, noise_std, scale, param, exp_avg, exp_avg_sq,
                      reinterpret_cast<bf16_t*>(shadow_bf16), grad_out, n, lr, beta1, beta2, eps,
-                     weight_decay, step);
+                     weight_decay, step, step_advance);
   VQAF_LAUNCH_CHECK();
 }
 
 extern "C" int vqaf_groupnorm_fwd(const void* x, const void* gamma, const void* beta, int B, int C,
                                   int groups, float eps, int relu, int dtype, void* y, void* xhat,
-                                  float* rstd, vqaf_stream_t stream) {
+                                  float* rstd, float dropout_p, uint64_t dropout_seed,
+                                  const uint64_t* dropout_counter, vqaf_stream_t stream) {
   VQAF_ENTRY();
   VQAF_REQUIRE(x && gamma && beta && y && xhat && rstd, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && C > 0 && gn_shape_ok(C, groups), VQAF_E_SHAPE);
+  VQAF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, VQAF_E_SHAPE);
+  VQAF_REQUIRE(dropout_p == 0.f || (dropout_counter != nullptr && relu), VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_aligned16(x) && vqaf_aligned16(y) && vqaf_aligned16(xhat) &&
                    vqaf_aligned16(gamma) && vqaf_aligned16(beta), VQAF_E_ALIGN);
   VQAF_BY_DTYPE(groupnorm_fwd_kernel, dim3(B), dim3(DP_THREADS), (hipStream_t)stream, x, gamma,
-                beta, C, groups, eps, relu, y, xhat, rstd);
+                beta, C, groups, eps, relu, y, xhat, rstd, dropout_p, (unsigned long long)dropout_seed,
+                dropout_p > 0.f ? dropout_counter : nullptr);
   VQAF_LAUNCH_CHECK();
 }
 
 extern "C" int vqaf_groupnorm_bwd(const void* grad_y, const void* y, const void* xhat,
                                   const float* rstd, const void* gamma, int B, int C, int groups,
-                                  int relu, int dtype, void* g_pre, void* grad_x,
+                                  int relu, float out_scale, int dtype, void* g_pre, void* grad_x,
                                   vqaf_stream_t stream) {
   VQAF_ENTRY();
   VQAF_REQUIRE(grad_y && xhat && rstd && gamma && g_pre && grad_x, VQAF_E_NULL);
   VQAF_REQUIRE(!relu || y != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(relu || out_scale == 1.0f, VQAF_E_SHAPE);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && C > 0 && gn_shape_ok(C, groups), VQAF_E_SHAPE);
   VQAF_REQUIRE(vqaf_aligned16(grad_y) && vqaf_aligned16(xhat) && vqaf_aligned16(g_pre) &&
                    vqaf_aligned16(grad_x) && vqaf_aligned16(gamma), VQAF_E_ALIGN);
   VQAF_BY_DTYPE(groupnorm_bwd_kernel, dim3(B), dim3(DP_THREADS), (hipStream_t)stream, grad_y, y,
-                xhat, rstd, gamma, C, groups, relu, g_pre, grad_x);
+                xhat, rstd, gamma, C, groups, relu, out_scale, g_pre, grad_x);
   VQAF_LAUNCH_CHECK();
 }
 

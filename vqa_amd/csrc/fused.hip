@@ -74,8 +74,8 @@ __device__ __forceinline__ void unpack_bf16x8(const u32x4 r, float (&v)[8]) {
 
 template <int STEPS>
 __global__ void __launch_bounds__(FU_THREADS, (STEPS <= 16 ? 4 : 2))
-fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, const uint64_t* __restrict__ sel_rng,
-                        void* __restrict__ out, int ld_out, int out_bf16) {
+fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, uint64_t* sel_rng,
+                        void* __restrict__ out, int ld_out, int out_bf16, int rng_advance) {
   // Modalities along y: every long (vision) sample is dispatched before the short (text) ones,
   // which then fill the tail of the launch.  Measured alternatives, both slower: alternating the
   // modalities in dispatch order (+22 us at B = 1024: the last long samples start late), and one
@@ -273,15 +273,19 @@ fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, const uint64_t* __rest
     if (out_bf16) reinterpret_cast<bf16_t*>(out)[o] = f32_to_bf16(r);
     else reinterpret_cast<float*>(out)[o] = r;
   }
+  // every draw of this workgroup (selection above, noise in pass 2) has read the state by now
+  if (rng_advance != 0)
+    vqaf_rng_bump_by_last_workgroup(sel_rng, (unsigned long long)rng_advance, gridDim.x * gridDim.y);
 }
 
 }  // namespace
 
 extern "C" int vqaf_fused_prune_pool_multi(const vqaf_fused_mod* mods_host, int n_mod, int B, int D, int H,
-                                           int dtype, const uint64_t* sel_rng_state, void* out, int ld_out,
-                                           int out_dtype, vqaf_stream_t stream) {
+                                           int dtype, uint64_t* sel_rng_state, int rng_advance, void* out,
+                                           int ld_out, int out_dtype, vqaf_stream_t stream) {
   VQAF_ENTRY();
   VQAF_REQUIRE(mods_host != nullptr && out != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(rng_advance >= 0 && (rng_advance == 0 || sel_rng_state != nullptr), VQAF_E_NULL);
   VQAF_REQUIRE(dtype == VQAF_BF16 && vqaf_dtype_ok(out_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(n_mod > 0 && n_mod <= FU_MAX_MODS && B > 0 && H > 0 && H <= 8, VQAF_E_SHAPE);
   VQAF_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512 || D == 1024, VQAF_E_SHAPE);
@@ -319,7 +323,7 @@ extern "C" int vqaf_fused_prune_pool_multi(const vqaf_fused_mod* mods_host, int 
   hipStream_t st = (hipStream_t)stream;
   const int obf = out_dtype == VQAF_BF16 ? 1 : 0;
 #define VQAF_FU(S) \
-  hipLaunchKernelGGL(fused_prune_pool_kernel<S>, grid, block, smem, st, mods, n_mod, H, sel_rng_state, out, ld_out, obf)
+  hipLaunchKernelGGL(fused_prune_pool_kernel<S>, grid, block, smem, st, mods, n_mod, H, sel_rng_state, out, ld_out, obf, rng_advance)
   switch (D / 32) {
     case 2: VQAF_FU(2); break;
     case 4: VQAF_FU(4); break;

@@ -151,7 +151,7 @@ class _GhostGroupNorm(torch.autograd.Function):
     gradient at the affine output."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, relu, tape):
+    def forward(ctx, x, weight, bias, groups, eps, relu, tape, drop_p=0.0, drop_seed=0, drop_counter=None):
         B, C = x.shape
         xc = x.contiguous()
         ga = _as_dtype(weight.detach(), x.dtype, tape.shadow).contiguous()
@@ -160,26 +160,28 @@ class _GhostGroupNorm(torch.autograd.Function):
         xhat = torch.empty_like(xc)
         rstd = torch.empty(B, groups, dtype=torch.float32, device=x.device)
         check(load().vqaf_groupnorm_fwd(ptr(xc), ptr(ga), ptr(be), B, C, groups, float(eps), int(relu),
-                                        dtype_code(xc), ptr(y), ptr(xhat), ptr(rstd),
+                                        dtype_code(xc), ptr(y), ptr(xhat), ptr(rstd), float(drop_p),
+                                        int(drop_seed) & 0xFFFFFFFFFFFFFFFF,
+                                        ptr(drop_counter) if drop_p > 0 else None,
                                         stream_ptr(x.device)), "vqaf_groupnorm_fwd")
         ctx.save_for_backward(y, xhat, rstd, ga)
-        ctx.meta = (B, C, groups, int(relu))
+        ctx.meta = (B, C, groups, int(relu), 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0)
         ctx.tape = tape
         return y
 
     @staticmethod
     def backward(ctx, gy):
         y, xhat, rstd, ga = ctx.saved_tensors
-        B, C, groups, relu = ctx.meta
+        B, C, groups, relu, out_scale = ctx.meta
         gy = gy.contiguous().to(y.dtype)
         g_pre = torch.empty_like(y)
         gx = torch.empty_like(y)
         check(load().vqaf_groupnorm_bwd(ptr(gy), ptr(y), ptr(xhat), ptr(rstd), ptr(ga), B, C, groups,
-                                        relu, dtype_code(y), ptr(g_pre), ptr(gx),
+                                        relu, float(out_scale), dtype_code(y), ptr(g_pre), ptr(gx),
                                         stream_ptr(y.device)), "vqaf_groupnorm_bwd")
         ctx.tape.a = xhat
         ctx.tape.g = g_pre
-        return gx, None, None, None, None, None, None
+        return gx, None, None, None, None, None, None, None, None, None
 
 
 class GradSampleModule(nn.Module):
@@ -198,6 +200,9 @@ class GradSampleModule(nn.Module):
         self.tapes: List[_Tape] = []
         self.last_batch_size = 0
         self.shadow = None  # data_ptr of an f32 parameter -> its bf16 copy (set by DPOptimizer)
+        self.dropout_rng = None  # seed (and fallback counter) of the fused dropout masks (made on first use)
+        self.step_counter = None  # {unused, steps} device words of the attached DP optimizer's fused update
+        self._drop_calls = 0      # dropout call sites since the last optimizer step
 
     def forward(self, x):
         self.tapes = []
@@ -212,8 +217,19 @@ class GradSampleModule(nn.Module):
                 c = children[i]
                 if isinstance(c, nn.GroupNorm) and i + 1 < len(children) and \
                         isinstance(children[i + 1], nn.ReLU) and x.dim() == 2:
-                    x = self._groupnorm(c, x, relu=True)
-                    i += 2
+                    # GroupNorm -> ReLU (-> Dropout) in one launch (model/model.py:56-58)
+                    drop = children[i + 2] if i + 2 < len(children) and \
+                        isinstance(children[i + 2], nn.Dropout) else None
+                    if drop is not None:
+                        p = float(drop.p) if (drop.training and 0.0 < drop.p < 1.0) else 0.0
+                        if drop.training and drop.p >= 1.0:
+                            drop = None  # p = 1 zeroes everything: leave it to nn.Dropout
+                    if drop is not None:
+                        x = self._groupnorm(c, x, relu=True, drop_p=p)
+                        i += 3
+                    else:
+                        x = self._groupnorm(c, x, relu=True)
+                        i += 2
                     continue
                 x = self._run(c, x)
                 i += 1
@@ -230,12 +246,27 @@ class GradSampleModule(nn.Module):
             return m(x)  # ReLU, Dropout, Identity ...: parameter-free, plain autograd
         raise ValueError(f"{type(m).__name__} has parameters but no per-sample rule")
 
-    def _groupnorm(self, m: nn.GroupNorm, x, relu: bool):
+    def _groupnorm(self, m: nn.GroupNorm, x, relu: bool, drop_p: float = 0.0):
         if x.dim() != 2 or not m.affine:
             raise ValueError("per-sample rule implemented for affine GroupNorm on (B, C) input")
         tape = _Tape(m, "affine", self.shadow)
         self.tapes.append(tape)
-        return _GhostGroupNorm.apply(x, m.weight, m.bias, m.num_groups, m.eps, relu, tape)
+        seed, counter = 0, None
+        if drop_p > 0.0:
+            if self.dropout_rng is None or self.dropout_rng.state.device != x.device:
+                self.dropout_rng = ops.PhiloxState(x.device, stream_salt=29)  # seeded from torch's global seed
+            # The mask stream is (seed + call site, step count).  With a DP optimizer attached the count
+            # is the one its fused update keeps in device memory (it moves once per step, so no launch
+            # is spent on a counter here and a replayed HIP graph draws fresh masks); the call-site
+            # index tells apart the dropout layers and repeated forwards of one step.  Without one the
+            # module's own counter is used and bumped after each forward.
+            counter = self.step_counter if self.step_counter is not None else self.dropout_rng.state
+            seed = self.dropout_rng.seed + 0x9E3779B97F4A7C15 * (1 + self._drop_calls)
+            self._drop_calls += 1
+        y = _GhostGroupNorm.apply(x, m.weight, m.bias, m.num_groups, m.eps, relu, tape, drop_p, seed, counter)
+        if drop_p > 0.0 and self.step_counter is None:
+            self.dropout_rng.advance()
+        return y
 
 
 # --------------------------------------------------------------------------------------------
@@ -411,6 +442,7 @@ class DPOptimizer:
             src, std, scale = S, self.noise_multiplier * self.max_grad_norm, 1.0 / self.expected_batch_size
         else:
             src, std, scale, noise = grad, 0.0, 1.0, None
+        single = len(self.original_optimizer.param_groups) == 1
         for group in self.original_optimizer.param_groups:
             ps = [p for p in group["params"] if id(p) in self._offsets]
             if not ps:
@@ -419,16 +451,19 @@ class DPOptimizer:
             hi = max(self._offsets[id(p)] + (p.numel() + 3) // 4 * 4 for p in ps)
             b1, b2 = group["betas"]
             nz = noise[lo:hi] if noise is not None else None
-            single = len(self.original_optimizer.param_groups) == 1
             noise_state = self._step if single else self._rng.state
             check(lib.vqaf_dp_adamw(ptr(src[lo:hi]), ptr(nz), ptr(noise_state), std, scale,
                                     ptr(self._P[lo:hi]), ptr(self._M[lo:hi]), ptr(self._V[lo:hi]),
                                     ptr(self._shadow[lo:hi]), ptr(grad[lo:hi]), hi - lo, float(group["lr"]),
                                     float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                    ptr(self._step), st), "vqaf_dp_adamw")
+                                    ptr(self._step), 0, st), "vqaf_dp_adamw")
             if world == 1 and nz is None and std != 0.0 and not single:
                 self._rng.advance()  # several groups: a fresh stream for the next group / step
+        # (step_advance = 1 would count the step in the kernel, but its returning device-scope atomic per
+        # workgroup costs more than this one-thread launch at 4096 short workgroups)
         check(lib.vqaf_rng_advance(ptr(self._step), 1, st), "vqaf_rng_advance")
+        self.module.step_counter = self._step
+        self.module._drop_calls = 0
 
     def _fused_step(self, noise: Optional[torch.Tensor] = None):
         """(tests) fused path with an injected noise tensor, after clip_and_accumulate()."""
@@ -500,6 +535,24 @@ class DPOptimizer:
             check(lib.vqaf_clip_coef(ptr(sq), B, max_norm, scale, ptr(coef), ptr(norms), st),
                   "vqaf_clip_coef")
         self.last_norms, self._last_coef, self._last_scale = norms, coef, scale
+        # Sums that are built with atomic adds (the affine sums; a Linear whose bf16 sum is split over
+        # the batch) start from zero: one launch zeroes all their slices, instead of a memset each.
+        zero = []
+        for t in tapes:
+            m = t.module
+            if t.kind != "linear":
+                zero += [self._slice(S, m.weight), self._slice(S, m.bias)]
+            elif t.g.dtype == torch.bfloat16 and not (
+                    prescaled and t.a.dtype == torch.bfloat16 and
+                    ops.gemm_bf16_supported(t.g.shape[1], True, t.a.shape[1], True, t.g.shape[1], t.a.shape[1], B)):
+                zero += [self._slice(S, m.weight)] + ([self._slice(S, m.bias)] if m.bias is not None else [])
+        pre_zeroed = 0 < len(zero) <= 8
+        if pre_zeroed:
+            import ctypes
+            zp = (ctypes.c_void_p * len(zero))(*[ptr(z) for z in zero])
+            zn = (ctypes.c_size_t * len(zero))(*[z.numel() for z in zero])
+            check(lib.vqaf_zero_multi(zp, zn, len(zero), st), "vqaf_zero_multi")
+        acc = 1 if pre_zeroed else 0
         for t in tapes:
             a, g = t.a, t.g.contiguous()
             m = t.module
@@ -515,12 +568,13 @@ class DPOptimizer:
                 else:
                     ops._probe(probe, "begin")
                     check(lib.vqaf_clipped_sum_linear(ptr(a), ptr(g), None if prescaled else ptr(coef), B,
-                                                      In_, Out_, dtype_code(g), 0, ptr(sw), ptr(sb), st),
+                                                      In_, Out_, dtype_code(g),
+                                                      acc if g.dtype == torch.bfloat16 else 0, ptr(sw), ptr(sb), st),
                           "vqaf_clipped_sum_linear")
                     ops._probe(probe, "end")
             else:
                 check(lib.vqaf_clipped_sum_affine(ptr(a), ptr(g), None if prescaled else ptr(coef), B, g.shape[1],
-                                                  dtype_code(g), 0, ptr(self._slice(S, m.weight)),
+                                                  dtype_code(g), acc, ptr(self._slice(S, m.weight)),
                                                   ptr(self._slice(S, m.bias)), st),
                       "vqaf_clipped_sum_affine")
         for t in tapes:  # the recorded backprops were scaled in place: they are spent

@@ -18,11 +18,12 @@ from ._lib import check, dtype_code, load, ptr, stream_ptr
 # Device-side counter-based RNG state {seed, counter}
 # --------------------------------------------------------------------------------------------
 class PhiloxState:
-    """Two 64-bit words in device memory: {seed, counter}.
+    """Four 64-bit words in device memory: {seed, counter, ticket, reserved}.
 
-    Kernels that draw random numbers read the pair and address each draw by
+    Kernels that draw random numbers read {seed, counter} and address each draw by
     (seed, counter, element); ``advance()`` bumps the counter on the stream, so a captured HIP
-    graph draws fresh numbers on every replay.
+    graph draws fresh numbers on every replay.  Kernels that bump the counter themselves (their last
+    workgroup does it) count arrivals in `ticket`, which is zero between launches.
     """
 
     def __init__(self, device: torch.device, seed: Optional[int] = None, stream_salt: int = 0):
@@ -30,7 +31,7 @@ class PhiloxState:
             seed = torch.initial_seed()
         self.seed = (int(seed) + 0x9E3779B97F4A7C15 * int(stream_salt)) & 0xFFFFFFFFFFFFFFFF
         signed = self.seed - (1 << 64) if self.seed >= (1 << 63) else self.seed
-        self.state = torch.tensor([signed, 0], dtype=torch.int64, device=device)
+        self.state = torch.tensor([signed, 0, 0, 0], dtype=torch.int64, device=device)
 
     def advance(self, delta: int = 1) -> None:
         check(load().vqaf_rng_advance(ptr(self.state), delta, stream_ptr(self.state.device)),
@@ -50,6 +51,8 @@ def default_rng(device: torch.device) -> PhiloxState:
         _default_states[key] = st
     return st[1]
 
+
+IN_KERNEL_RNG_BUMP = False  # let vqaf_fused_prune_pool_multi advance its generator state itself
 
 # Optional measurement probe: bench.py installs a callable (name, phase) -> None that records
 # stream events around a named kernel launch; None in normal use.
@@ -541,7 +544,7 @@ class _FusedPrunePool(torch.autograd.Function):
     The backward is the pooled prune/mix backward (scores and indices carry no gradient)."""
 
     @staticmethod
-    def forward(ctx, n_mod, out_dtype, rng_state, *flat):
+    def forward(ctx, n_mod, out_dtype, rng_state, rng_advance, sel_draws, *flat):
         import ctypes
         per = 14
         mods = [flat[i * per:(i + 1) * per] for i in range(n_mod)]
@@ -577,7 +580,7 @@ class _FusedPrunePool(torch.autograd.Function):
             fm[i] = _lib.FusedMod(ptr(seq_c), ptr(u), ptr(pos) if mode == 1 else None, ptr(src) if mode == 1 else None,
                                   ptr(noise_c), ptr(noise_state), ptr(idx), None, int(salt), float(alpha),
                                   float(noise_scale), int(kind), N, int(k), mode, int(k_adv), i * D,
-                                  int(rng_state is not None and noise_state is not None
+                                  int(sel_draws and rng_state is not None and noise_state is not None
                                       and noise_state.data_ptr() == rng_state.data_ptr()))
             idxs.append(idx)
             metas.append((N, int(k), D, float(alpha), seq.dtype, i * D))
@@ -585,12 +588,13 @@ class _FusedPrunePool(torch.autograd.Function):
                                         _lib.BF16 if w_dt == torch.bfloat16 else _lib.F32, st), "vqaf_fold_query_multi")
         _probe("fused_prune_pool", "begin")
         check(lib.vqaf_fused_prune_pool_multi(ctypes.cast(fm, ctypes.c_void_p), n_mod, B, D, H, dtype_code(seq0),
-                                              ptr(rng_state), ptr(out), ld, dtype_code(out), st),
+                                              ptr(rng_state), int(rng_advance), ptr(out), ld, dtype_code(out), st),
               "vqaf_fused_prune_pool_multi")
         _probe("fused_prune_pool", "end")
-        for (_s, _q, _w, _b, _qp, _u, _p, _sr, noise_c, noise_state), m in zip(keep, mods):
-            if noise_state is not None and m[12] != _lib.NOISE_NONE and noise_c is None:
-                check(lib.vqaf_rng_advance(ptr(noise_state), 1, st), "vqaf_rng_advance")
+        if not rng_advance:  # the kernel did not bump the counter itself: one launch per noise stream
+            for (_s, _q, _w, _b, _qp, _u, _p, _sr, noise_c, noise_state), m in zip(keep, mods):
+                if noise_state is not None and m[12] != _lib.NOISE_NONE and noise_c is None:
+                    check(lib.vqaf_rng_advance(ptr(noise_state), 1, st), "vqaf_rng_advance")
         ctx.save_for_backward(*idxs)
         ctx.metas = metas
         ctx.B, ctx.ld, ctx.n_mod, ctx.per = B, ld, n_mod, per
@@ -602,14 +606,14 @@ class _FusedPrunePool(torch.autograd.Function):
     def backward(ctx, grad_out, *_unused):
         import ctypes
         if grad_out is None:
-            return (None,) * (3 + ctx.per * ctx.n_mod)
+            return (None,) * (5 + ctx.per * ctx.n_mod)
         g = grad_out.contiguous()
         if g.dtype not in (torch.float32, torch.bfloat16):
             g = g.float()
         lib, st = load(), stream_ptr(g.device)
         outs = []
         for i, (N, K, D, alpha, sdt, col0) in enumerate(ctx.metas):
-            need = ctx.needs_input_grad[3 + ctx.per * i]
+            need = ctx.needs_input_grad[5 + ctx.per * i]
             outs.append(torch.empty(ctx.B, N, D, dtype=sdt, device=g.device) if need else None)
         if any(o is not None for o in outs):
             arr = (_lib.PoolBwdMod * ctx.n_mod)()
@@ -618,7 +622,7 @@ class _FusedPrunePool(torch.autograd.Function):
             check(lib.vqaf_gather_mix_pool_bwd_multi(ptr(g), ctx.ld, dtype_code(g), ctypes.cast(arr, ctypes.c_void_p),
                                                      ctx.n_mod, ctx.B, ctx.metas[0][2], _lib.BF16, st),
                   "vqaf_gather_mix_pool_bwd_multi")
-        grads = [None, None, None]
+        grads = [None, None, None, None, None]
         for o in outs:
             grads.extend([o] + [None] * (ctx.per - 1))
         return tuple(grads)
@@ -627,13 +631,14 @@ class _FusedPrunePool(torch.autograd.Function):
 def fused_prune_pool(specs, out_dtype: torch.dtype, rng: Optional["PhiloxState"] = None):
     """specs: list of dicts(q, seq, in_proj_weight, in_proj_bias, num_heads, k, k_adv, pos, src, salt,
     alpha, noise, noise_type, noise_scale, noise_rng).  Returns (fused, [keep indices], drew)."""
-    flat, drew = [], False
+    flat, drew, noise_states = [], False, []
     dev = specs[0]["seq"].device
     for i, sp in enumerate(specs):
         kind = _noise_kind(sp.get("noise_type")) if sp.get("noise") is None else _lib.NOISE_NONE
         state = None
         if kind != _lib.NOISE_NONE:
             state = (sp.get("noise_rng") or default_rng(dev)).state
+            noise_states.append(state)
         k_adv = int(sp.get("k_adv", 0))
         if k_adv > 0 and sp.get("pos") is None:
             drew = True
@@ -642,8 +647,17 @@ def fused_prune_pool(specs, out_dtype: torch.dtype, rng: Optional["PhiloxState"]
                      (sp.get("noise_scale", 0.0), state)])
     if drew and rng is None:
         rng = default_rng(dev)
-    res = _FusedPrunePool.apply(len(specs), out_dtype, rng.state if drew else None, *flat)
-    return res[0], list(res[1:]), drew
+    # Every stream this launch draws from: the selection's and the in-kernel noise streams.  When
+    # they are one and the same state the kernel's last workgroup bumps its counter (once per
+    # stream position consumed) and no counter launch follows; the caller then has nothing to advance.
+    streams = list(noise_states) + ([rng.state] if drew else [])
+    # (off by default: the bump costs every workgroup a returning device-scope atomic at its end, which
+    # at thousands of workgroups per launch is slower than the one-thread launch it saves)
+    in_kernel = IN_KERNEL_RNG_BUMP and bool(streams) and streams[0].numel() >= 4 and \
+        all(t.data_ptr() == streams[0].data_ptr() for t in streams)
+    res = _FusedPrunePool.apply(len(specs), out_dtype, streams[0] if in_kernel else (rng.state if drew else None),
+                                len(streams) if in_kernel else 0, drew, *flat)
+    return res[0], list(res[1:]), drew and not in_kernel
 
 
 def pruned_pool(mods, out_dtype: torch.dtype) -> torch.Tensor:
