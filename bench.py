@@ -155,7 +155,7 @@ def make_step(fus, gsm, opt, main_opt, sets):
         fused = fus(v, vg, q, qg)
         logits = gsm(fused)
         loss = ops.cross_entropy_mean(logits, y)
-        loss.backward()
+        loss.backward(gradient=ops.unit_gradient(loss))
         main_opt.step()
         opt.local_step()
         return loss

@@ -486,6 +486,12 @@ int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, int C, int d
                  float* loss, float* conf, int64_t* pred, float* grad_logits, float grad_scale,
                  vqaf_stream_t stream);
 
+/* out[i] = in[i] * scale[0] (scale in device memory), written as `out_dtype`: the backward of the
+ * mean cross-entropy of utils/src.py:96 -- the logits gradient vqaf_ce_conf produced in the forward
+ * pass times the incoming scalar gradient, rounded once into the logits' dtype. */
+int vqaf_scale_cast(const float* in, const float* scale, size_t n, int out_dtype, void* out,
+                    vqaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -849,6 +849,24 @@ ce_conf_kernel(const void* __restrict__ logits, const int64_t* __restrict__ targ
   }
 }
 
+// out[i] = in[i] * scale[0] in the requested dtype: the chain-rule factor of a loss whose logits
+// gradient the forward already produced (one pass, eight elements per lane).
+template <bool BF16>
+__global__ void __launch_bounds__(DP_THREADS)
+scale_cast_kernel(const float* __restrict__ in, const float* __restrict__ scale, size_t n, void* __restrict__ out) {
+  const float s = scale[0];
+  const size_t n8 = n / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    float v[8];
+    load8<false>(in, i * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= s;
+    store8<BF16>(out, i * 8, v);
+  }
+  for (size_t i = n8 * 8 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    store1<BF16>(out, i, in[i] * s);
+}
+
 bool gn_shape_ok(int C, int groups) {
   if (groups <= 0 || C % groups != 0) return false;
   const int gs = C / groups;
@@ -1155,6 +1173,20 @@ extern "C" int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, i
   VQAF_BY_DTYPE(ce_conf_kernel, dim3((B + rows_per_block - 1) / rows_per_block), dim3(DP_THREADS),
                 (hipStream_t)stream, logits, targets, B, C, loss, conf, pred, grad_logits,
                 grad_scale);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_scale_cast(const float* in, const float* scale, size_t n, int out_dtype, void* out,
+                               vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(in && scale && out, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(out_dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(n > 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_aligned16(in) && vqaf_aligned16(out), VQAF_E_ALIGN);
+  size_t blocks = (n / 8 + DP_THREADS - 1) / DP_THREADS;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  const int dtype = out_dtype;
+  VQAF_BY_DTYPE(scale_cast_kernel, dim3((unsigned)blocks), dim3(DP_THREADS), (hipStream_t)stream, in, scale, n, out);
   VQAF_LAUNCH_CHECK();
 }
 

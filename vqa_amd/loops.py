@@ -14,6 +14,8 @@ from typing import Dict, Tuple
 import torch
 import torch.nn as nn
 
+from . import ops
+
 
 def _batch(batch, device):
     inputs = batch['inputs']
@@ -48,7 +50,7 @@ def train(model: nn.Module, train_loader, optimizer, criterion, device, model_ty
             optimizer.zero_grad()
         outputs = model(images=images, input_ids=ids, attention_mask=mask)   # :91-95
         loss = criterion(outputs, answers)                                   # :96
-        loss.backward()                                                      # :99
+        loss.backward(gradient=ops.unit_gradient(loss))                      # :99 (the same unit gradient, cached)
         if split:                                                            # :102-106
             optimizer['main'].step()
             optimizer['classifier'].step()

@@ -709,12 +709,31 @@ class _MeanCE(torch.autograd.Function):
     def backward(ctx, grad_out):
         (grad,) = ctx.saved_tensors
         # one launch: the product is rounded straight into the logits' dtype
-        out = torch.empty(grad.shape, dtype=ctx.in_dtype, device=grad.device)
-        return torch.mul(grad, grad_out, out=out), None
+        if ctx.in_dtype in (torch.float32, torch.bfloat16) and grad_out.numel() == 1:
+            out = torch.empty(grad.shape, dtype=ctx.in_dtype, device=grad.device)
+            go = grad_out.reshape(1).to(torch.float32)  # a view for the usual f32 scalar
+            check(load().vqaf_scale_cast(ptr(grad), ptr(go), grad.numel(), dtype_code(out), ptr(out),
+                                         stream_ptr(grad.device)), "vqaf_scale_cast")
+            return out, None
+        return (grad * grad_out).to(ctx.in_dtype), None
 
 
 def cross_entropy_mean(logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
     return _MeanCE.apply(logits, targets)
+
+
+_unit_grads: dict = {}
+
+
+def unit_gradient(loss: torch.Tensor) -> torch.Tensor:
+    """A cached scalar 1 of the loss's dtype and device for `loss.backward(gradient=...)`: what
+    `loss.backward()` uses, without the fill launch autograd spends on making it every step."""
+    key = (loss.device, loss.dtype)
+    one = _unit_grads.get(key)
+    if one is None:
+        one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        _unit_grads[key] = one
+    return one
 
 
 def gemm_bf16_supported(lda: int, a_kmajor: bool, ldb: int, b_kmajor: bool, M: int, N: int, K: int) -> bool:
