@@ -254,7 +254,10 @@ class GradSampleModule(nn.Module):
         seed, counter = 0, None
         if drop_p > 0.0:
             if self.dropout_rng is None or self.dropout_rng.state.device != x.device:
-                self.dropout_rng = ops.PhiloxState(x.device, stream_salt=29)  # seeded from torch's global seed
+                import torch.distributed as dist
+                rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+                # seeded from torch's global seed; ranks that share it still draw different masks
+                self.dropout_rng = ops.PhiloxState(x.device, stream_salt=29 + 1009 * rank)
             # The mask stream is (seed + call site, step count).  With a DP optimizer attached the count
             # is the one its fused update keeps in device memory (it moves once per step, so no launch
             # is spent on a counter here and a replayed HIP graph draws fresh masks); the call-site
