@@ -354,6 +354,16 @@ int vqaf_gemm_f32(const void* A, int a_dtype, long a_sg, long a_sm, long a_sk, c
                   long bias_sg, float* C, long c_sg, long c_sm, int G, int M, int N, int K,
                   float alpha, int beta_one, vqaf_stream_t stream);
 
+/* The same product, free to split a long contraction over workgroups that add their parts into C with
+ * f32 atomics when the output has only a few tiles (M, N small next to K: the (B,E)-sized projections
+ * of the dense branch and their weight gradients at small batches).  The sum then depends on the order
+ * the parts arrive in: equal to vqaf_gemm_f32 within f32 rounding, not bit for bit, so it serves
+ * gradients and activations, never the scoring path whose results rank tokens. */
+int vqaf_gemm_f32_atomic(const void* A, int a_dtype, long a_sg, long a_sm, long a_sk, const void* Bm,
+                  int b_dtype, long b_sg, long b_sk, long b_sn, const void* bias, int bias_dtype,
+                  long bias_sg, float* C, long c_sg, long c_sm, int G, int M, int N, int K,
+                  float alpha, int beta_one, vqaf_stream_t stream);
+
 /* bf16 GEMM on the matrix cores for the classifier's three uses of a Linear under DP-SGD
  * (model/model.py:54-63 wrapped at train.py:124-141):
  *   C[m][n] = sum_k A(m,k) B(k,n) (+ bias[n]),   f32 accumulation,

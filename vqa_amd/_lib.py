@@ -104,6 +104,9 @@ SIGNATURES = {
     "vqaf_gemm_f32": (c_int, [_P, c_int, c_long, c_long, c_long, _P, c_int, c_long, c_long, c_long,
                               _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
                               c_float, c_int, _P]),
+    "vqaf_gemm_f32_atomic": (c_int, [_P, c_int, c_long, c_long, c_long, _P, c_int, c_long, c_long, c_long,
+                                     _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
+                                     c_float, c_int, _P]),
     "vqaf_gemm_bf16_supported": (c_int, [c_long, c_int, c_long, c_int, c_int, c_int, c_int]),
     "vqaf_gemm_bf16": (c_int, [_P, c_long, c_int, _P, c_long, c_int, c_int, c_int, c_int, _P, c_int, _P, c_long,
                                c_int, c_int, _P, _P]),

@@ -115,16 +115,22 @@ struct GemmSets {
 template <int AMODE, int BMODE, bool A_BF16, bool B_BF16>
 __global__ void __launch_bounds__(GTHREADS)
 gemm_f32_kernel(GemmSets sets, long a_sg, long a_sm, long a_sk, long b_sg, long b_sk, long b_sn,
-                int bias_bf16, long bias_sg, long c_sg, long c_sm, int M, int N, int K, float alpha,
-                int beta_one) {
+                int bias_bf16, long bias_sg, long c_sg, long c_sm, int M, int N, int K_total, float alpha,
+                int beta_one, int splits, int k_per_split) {
   __shared__ float As[2][GK][GP];
   __shared__ float Bs[2][GK][GP];
-  const int set = blockIdx.z / sets.gper;
+  // blockIdx.z = (set * gper + g) * splits + kz: a split owns k in [kz * k_per_split, ...) and adds its
+  // part into C atomically (the launcher has zeroed C unless it accumulates anyway)
+  const int kz = blockIdx.z % splits;
+  const int zb = blockIdx.z / splits;
+  const int k_lo = kz * k_per_split;
+  const int K = min(K_total, k_lo + k_per_split);  // this split's upper bound (loads clamp to it)
+  const int set = zb / sets.gper;
   const void* __restrict__ A = sets.A[set];
   const void* __restrict__ Bm = sets.Bm[set];
   const void* __restrict__ bias = sets.bias[set];
   float* __restrict__ C = sets.C[set];
-  const int g = blockIdx.z % sets.gper, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = zb % sets.gper, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
   f32x16 acc;
@@ -134,13 +140,13 @@ gemm_f32_kernel(GemmSets sets, long a_sg, long a_sm, long a_sk, long b_sg, long 
   // register staging runs two stages ahead of the MFMAs (stage t lives in register set t & 1),
   // LDS is double buffered: the loads of stage s+2 are in flight while stage s is multiplied
   u32x4 ra[2][GVECS], rb[2][GVECS];
-  const int stages = (K + GK - 1) / GK;
-  fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, 0, K, tid, ra[0]);
-  fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, 0, K, tid, rb[0]);
-  fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, GK, K, tid, ra[1]);
-  fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, GK, K, tid, rb[1]);
-  store_tile<AMODE, A_BF16>(As[0], tid, ra[0], m0, M, 0, K);
-  store_tile<BMODE, B_BF16>(Bs[0], tid, rb[0], n0, N, 0, K);
+  const int stages = (K - k_lo + GK - 1) / GK;
+  fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, k_lo, K, tid, ra[0]);
+  fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, k_lo, K, tid, rb[0]);
+  fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, k_lo + GK, K, tid, ra[1]);
+  fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, k_lo + GK, K, tid, rb[1]);
+  store_tile<AMODE, A_BF16>(As[0], tid, ra[0], m0, M, k_lo, K);
+  store_tile<BMODE, B_BF16>(Bs[0], tid, rb[0], n0, N, k_lo, K);
   __syncthreads();
   // The loop body is branch-free (an odd stage count is padded with one all-zero stage: indices
   // are clamped on load and masked to zero on store), so every wait the compiler inserts is a
@@ -151,16 +157,16 @@ gemm_f32_kernel(GemmSets sets, long a_sg, long a_sm, long a_sk, long b_sg, long 
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
       const int t = s + P;
-      fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, (t + 2) * GK, K, tid, ra[P]);
-      fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, (t + 2) * GK, K, tid, rb[P]);
+      fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, k_lo + (t + 2) * GK, K, tid, ra[P]);
+      fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, k_lo + (t + 2) * GK, K, tid, rb[P]);
 #pragma unroll
       for (int kk = 0; kk < GK; kk += 2) {
         const float af = As[P][kk + (lane >> 5)][wm * 32 + (lane & 31)];
         const float bf = Bs[P][kk + (lane >> 5)][wn * 32 + (lane & 31)];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
       }
-      store_tile<AMODE, A_BF16>(As[P ^ 1], tid, ra[P ^ 1], m0, M, (t + 1) * GK, K);
-      store_tile<BMODE, B_BF16>(Bs[P ^ 1], tid, rb[P ^ 1], n0, N, (t + 1) * GK, K);
+      store_tile<AMODE, A_BF16>(As[P ^ 1], tid, ra[P ^ 1], m0, M, k_lo + (t + 1) * GK, K);
+      store_tile<BMODE, B_BF16>(Bs[P ^ 1], tid, rb[P ^ 1], n0, N, k_lo + (t + 1) * GK, K);
       __syncthreads();
     }
   }
@@ -171,11 +177,15 @@ gemm_f32_kernel(GemmSets sets, long a_sg, long a_sm, long a_sk, long b_sg, long 
     const int gn = n0 + wn * 32 + (lane & 31);
     if (gm < M && gn < N) {
       float v = alpha * acc[r];
-      if (bias != nullptr)
+      if (bias != nullptr && kz == 0)
         v += bias_bf16 ? load1<true>(bias, (size_t)((long)g * bias_sg + gn)) : load1<false>(bias, (size_t)((long)g * bias_sg + gn));
       float* c = C + (long)g * c_sg + gm * c_sm + gn;
-      if (beta_one) v += *c;
-      *c = v;
+      if (splits > 1) {
+        atomicAdd(c, v);
+      } else {
+        if (beta_one) v += *c;
+        *c = v;
+      }
     }
   }
 }
@@ -192,7 +202,7 @@ int pick_mode(const void* p, int dtype, long sg, long sx, long sk, int X, int K)
 // Launches `nsets` problems of identical shape / strides / dtypes in one grid.
 int gemm_launch(const GemmSets& sets, int nsets, int a_dtype, long a_sg, long a_sm, long a_sk, int b_dtype,
                 long b_sg, long b_sk, long b_sn, int bias_dtype, long bias_sg, long c_sg, long c_sm, int G,
-                int M, int N, int K, float alpha, int beta_one, hipStream_t st) {
+                int M, int N, int K, float alpha, int beta_one, hipStream_t st, bool allow_split = false) {
   VQAF_REQUIRE(nsets > 0 && nsets <= GEMM_MAX_SETS, VQAF_E_SHAPE);
   VQAF_REQUIRE(vqaf_dtype_ok(a_dtype) && vqaf_dtype_ok(b_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(G > 0 && M > 0 && N > 0 && K > 0 && (long)G * nsets <= 65535, VQAF_E_SHAPE);
@@ -207,13 +217,28 @@ int gemm_launch(const GemmSets& sets, int nsets, int a_dtype, long a_sg, long a_
     if (ai != am) am = G_SCALAR;  // the sets must share one staging mode
     if (bi != bm) bm = G_SCALAR;
   }
-  const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, G * nsets), block(GTHREADS);
-  VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);
+  // Few output tiles and a long contraction (the (B,E)-sized projections at small batches): where the
+  // caller allows it, split k over workgroups, which add their parts atomically (the sum then varies in
+  // its last bits from run to run, so the scoring path, whose results rank tokens, never asks for it).  Needs C zeroed first, which is one memset when
+  // the written elements form one dense block (plain row-major, or head slices that tile the rows).
+  int splits = 1;
+  const long tiles = (long)((N + GT - 1) / GT) * ((M + GT - 1) / GT) * G * nsets;
+  const bool dense_c = (c_sm == N && (G == 1 || c_sg == (long)M * N)) || (c_sg == N && c_sm == (long)G * N);
+  if (allow_split && tiles < 128 && K >= 4 * GK && (beta_one || dense_c)) {
+    while (splits < 16 && tiles * splits < 256 && K / (splits * 2) >= 2 * GK) splits *= 2;
+  }
+  const int k_per_split = ((K + splits - 1) / splits + GK - 1) / GK * GK;
+  if (splits > 1 && !beta_one) {
+    for (int i = 0; i < nsets; ++i)
+      if (hipMemsetAsync(sets.C[i], 0, (size_t)G * M * N * sizeof(float), st) != hipSuccess) return VQAF_E_LAUNCH;
+  }
+  const dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, G * nsets * splits), block(GTHREADS);
+  VQAF_REQUIRE(grid.y <= 65535 && grid.z <= 65535, VQAF_E_SHAPE);
   const int bias_bf16 = bias_dtype == VQAF_BF16;
   const bool ab = a_dtype == VQAF_BF16, bb = b_dtype == VQAF_BF16;
 #define VQAF_GEMM_LAUNCH(AM, BM_, AB, BB)                                                             \
   hipLaunchKernelGGL((gemm_f32_kernel<AM, BM_, AB, BB>), grid, block, 0, st, sets, a_sg, a_sm, a_sk,   \
-                     b_sg, b_sk, b_sn, bias_bf16, bias_sg, c_sg, c_sm, M, N, K, alpha, beta_one)
+                     b_sg, b_sk, b_sn, bias_bf16, bias_sg, c_sg, c_sm, M, N, K, alpha, beta_one, splits, k_per_split)
 #define VQAF_GEMM_BY_DT(AM, BM_)                            \
   do {                                                      \
     if (ab && bb) VQAF_GEMM_LAUNCH(AM, BM_, true, true);    \
@@ -254,6 +279,23 @@ extern "C" int vqaf_gemm_f32(const void* A, int a_dtype, long a_sg, long a_sm, l
   sets.gper = G;
   return gemm_launch(sets, 1, a_dtype, a_sg, a_sm, a_sk, b_dtype, b_sg, b_sk, b_sn, bias_dtype, bias_sg, c_sg,
                      c_sm, G, M, N, K, alpha, beta_one, (hipStream_t)stream);
+}
+
+extern "C" int vqaf_gemm_f32_atomic(const void* A, int a_dtype, long a_sg, long a_sm, long a_sk,
+                                    const void* Bm, int b_dtype, long b_sg, long b_sk, long b_sn,
+                                    const void* bias, int bias_dtype, long bias_sg, float* C, long c_sg,
+                                    long c_sm, int G, int M, int N, int K, float alpha, int beta_one,
+                                    vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(A != nullptr && Bm != nullptr && C != nullptr, VQAF_E_NULL);
+  GemmSets sets = {};
+  sets.A[0] = A;
+  sets.Bm[0] = Bm;
+  sets.bias[0] = bias;
+  sets.C[0] = C;
+  sets.gper = G;
+  return gemm_launch(sets, 1, a_dtype, a_sg, a_sm, a_sk, b_dtype, b_sg, b_sk, b_sn, bias_dtype, bias_sg, c_sg,
+                     c_sm, G, M, N, K, alpha, beta_one, (hipStream_t)stream, true);
 }
 
 // u_i (B,H,D) for several (query, in_proj) pairs of one shape: two launches in total (see
