@@ -502,6 +502,51 @@ int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, int C, int d
 int vqaf_scale_cast(const float* in, const float* scale, size_t n, int out_dtype, void* out,
                     vqaf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Encoder blocks: the transformer layers of the vision and text encoders whose outputs feed the
+ * fusion (model/vision_encoder.py:83-127 and model/text_encoder.py:14-48 wrap Hugging Face
+ * models; these are the per-layer operations of those models that are not plain GEMMs).
+ * ------------------------------------------------------------------------------------ */
+
+/* Multi-head self-attention, bf16, head size dh = 64:
+ *   out[b,n,64h:64h+64] = softmax_m(scale * q_bnh . k_bmh + key_bias[b,m]) v_bmh.
+ * q, k, v: (B, N, ld_qkv) bf16 with head h in columns [64h, 64h+64) (three tensors, or three column
+ * blocks of one packed projection output); key_bias (B,N) f32 additive or NULL (the extended
+ * attention mask of BertModel: 0 for tokens, a large negative number for padding); out (B, N, ld_o);
+ * lse (B,H,N) f32 receives the base-2 logarithm of the softmax denominator in the scaled domain
+ * (what vqaf_attn_bwd needs).  Row pitches are in elements and multiples of 8. */
+int vqaf_attn_fwd(const void* q, const void* k, const void* v, long ld_qkv, const float* key_bias,
+                  int B, int H, int N, int dh, float scale, void* out, long ld_o, float* lse,
+                  vqaf_stream_t stream);
+
+/* Backward of vqaf_attn_fwd: dq, dk, dv (B, N, ld_d) bf16 from dout (B, N, ld_o) and the forward's
+ * lse; the forward output itself is not needed (the row term of the softmax backward is recomputed
+ * from the probabilities, which keeps sum_m ds[n,m] = 0 to f32 rounding).  dvec (B,H,N) f32 is
+ * workspace. */
+int vqaf_attn_bwd(const void* q, const void* k, const void* v, long ld_qkv, const float* key_bias,
+                  const void* dout, long ld_o, const float* lse, int B, int H, int N,
+                  int dh, float scale, void* dq, void* dk, void* dv, long ld_d, float* dvec,
+                  vqaf_stream_t stream);
+
+/* LayerNorm over the last dimension with the residual add in front of it (nn.LayerNorm of the
+ * BertSelfOutput / BertOutput / ViTLayer blocks): s = x (+ residual), y = LN(s) * gamma + beta.
+ * x, residual (may be NULL), sum_out (may be NULL; receives s), y: (rows, D) `dtype`; gamma, beta
+ * (D) f32; mean, rstd (rows) f32 for the backward.  D <= 2048, D % 8 == 0. */
+int vqaf_layernorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long rows,
+                       int D, float eps, int dtype, void* sum_out, void* y, float* mean, float* rstd,
+                       vqaf_stream_t stream);
+
+/* Backward: dx (rows, D) = LayerNorm backward of dy at input s (+ dsum_in, the gradient that reaches
+ * s directly through a residual branch; may be NULL).  dgamma, dbeta (D) f32 are ACCUMULATED into
+ * (atomics): the caller zeroes them. */
+int vqaf_layernorm_bwd(const void* dy, const void* s, const float* gamma, const float* mean,
+                       const float* rstd, const void* dsum_in, long rows, int D, int dtype, void* dx,
+                       float* dgamma, float* dbeta, vqaf_stream_t stream);
+
+/* GELU in its exact (erf) form, the "gelu" activation of both encoder configs; n % 8 == 0. */
+int vqaf_gelu_fwd(const void* x, size_t n, int dtype, void* y, vqaf_stream_t stream);
+int vqaf_gelu_bwd(const void* x, const void* dy, size_t n, int dtype, void* dx, vqaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,713 @@
+// Transformer-encoder blocks for the two encoders that feed the fusion (ViT-B/16-shaped vision
+// encoder, BERT-base text encoder; the reference wraps Hugging Face models for both:
+// model/vision_encoder.py:83-127, model/text_encoder.py:14-48).
+//
+//   * multi-head self-attention, forward and backward, bf16 on v_mfma_f32_32x32x16_bf16 with an
+//     online softmax (scores never leave registers), head size 64;
+//   * LayerNorm with the residual add folded in, forward and backward;
+//   * exact (erf) GELU, forward and backward.
+// The Linear layers around them are plain GEMMs and stay with the BLAS library.
+//
+// Attention layout.  MFMA 32x32 accumulators give a lane ONE column and 16 rows, so every product
+// is arranged to put the softmax row (a query) on the column index: S^T = K Q^T, O^T = V^T P^T.
+// Row maxima and sums are then per-lane scalars plus one exchange between lane l and l+32, the
+// rescaling of O^T is a per-lane multiply, and the accumulator of S^T is, register for register,
+// the B operand of the second product (its 16 rows are the contraction index; their order inside
+// a 16-row step is a fixed permutation that the A operand is read with as well).  A operands
+// that need the contraction index down a column of a row-major tile (V^T, K^T, Q^T, dO^T) come
+// from LDS through the transposing read ds_read_b64_tr_b16.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AT_DH = 64;        // head size
+constexpr int AT_OWN = 128;      // rows (queries, or keys in the dK/dV kernel) owned by a workgroup: 4 waves x 32
+constexpr int AT_BLK = 64;       // streamed rows per stage
+constexpr int AT_PR = 72;        // LDS pitch (elements) of tiles read by rows: 16-B reads of 16 lanes hit 64 distinct banks
+constexpr int AT_PT = 96;        // LDS pitch of tiles read by the transposing read: its four rows fall on disjoint bank groups
+constexpr float AT_LOG2E = 1.4426950408889634f;
+constexpr float AT_MIN_BIAS = -1.0e30f;  // additive key bias is clamped here so that a fully masked row stays finite
+
+struct AttnArgs {
+  const bf16_t *q, *k, *v;   // (B, N, ld_qkv) each, head h in columns [64h, 64h+64)
+  const bf16_t *dout;        // (B, N, ld_o)
+  bf16_t *out;               // forward output (B, N, ld_o)
+  bf16_t *dq, *dk, *dv;      // (B, N, ld_d)
+  const float* key_bias;     // (B, N) additive, or null
+  float* lse;                // (B, H, N): log2 of the softmax denominator, in the scaled base-2 domain
+  float* dvec;               // (B, H, N): sum_m p[n,m] dp[n,m], the row term of the softmax backward
+  long ld_qkv, ld_o, ld_d;
+  int N, H;
+  float scale;               // 1/sqrt(dh)
+};
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) {
+  union { u32x4 u; bf16x8 b; } c; c.u = v; return c.b;
+}
+__device__ __forceinline__ float xchg32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  // one of the two results is the own value, the other the partner's
+  const unsigned int own = __float_as_uint(v);
+  return __uint_as_float(r[0] == own ? r[1] : r[0]);
+}
+// A operand whose contraction index runs down the rows of a row-major LDS tile (pitch AT_PT):
+// lane (i = lane%32, half = lane/32) receives column col0+i, rows row0 + 4*half + {0..3} and
+// row0 + 8 + 4*half + {0..3}: the row order of a 32x32 accumulator within a 16-row step.
+__device__ __forceinline__ bf16x8 tr_rows(const bf16_t* tile, int row0, int colbase, int lane) {
+  const int i = lane & 15;
+  const bf16_t* p0 = tile + (row0 + 4 * (lane >> 5) + (i >> 2)) * AT_PT + colbase + 16 * ((lane >> 4) & 1) + 4 * (i & 3);
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0 + 8 * AT_PT));
+  union { s16x8 s; bf16x8 b; } u;
+  u.s = s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return u.b;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int t) {
+  return bf16x8{(__bf16)v[8 * t + 0], (__bf16)v[8 * t + 1], (__bf16)v[8 * t + 2], (__bf16)v[8 * t + 3],
+                (__bf16)v[8 * t + 4], (__bf16)v[8 * t + 5], (__bf16)v[8 * t + 6], (__bf16)v[8 * t + 7]};
+}
+// accumulator register r of a lane in half hh belongs to row 8*(r/4) + 4*hh + r%4
+__device__ __forceinline__ int acc_row(int r, int hh) { return 8 * (r >> 2) + 4 * hh + (r & 3); }
+
+// Streams a 64-row block of a (N, ld) matrix (64 columns of one head) through registers.
+struct Stage {
+  u32x4 a[2];
+  __device__ __forceinline__ void issue(const bf16_t* base, long ld, int row0, int N, int tid) {
+    const int row = min(row0 + (tid >> 2), N - 1);
+    const bf16_t* p = base + (size_t)row * ld + (tid & 3) * 16;
+    a[0] = *reinterpret_cast<const u32x4*>(p);
+    a[1] = *reinterpret_cast<const u32x4*>(p + 8);
+  }
+  __device__ __forceinline__ void commit(bf16_t* tile, int pitch, int tid) const {
+    bf16_t* p = tile + (tid >> 2) * pitch + (tid & 3) * 16;
+    *reinterpret_cast<u32x4*>(p) = a[0];
+    *reinterpret_cast<u32x4*>(p + 8) = a[1];
+  }
+};
+
+// Transposed 64 x 32 accumulator pair (rows = head columns, lane column = the owned row) -> memory.
+__device__ __forceinline__ void store_owned(bf16_t* row_ptr, const f32x16 (&acc)[2], float mul, int hh) {
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2 w{pack_bf16x2(acc[d][4 * g] * mul, acc[d][4 * g + 1] * mul),
+                    pack_bf16x2(acc[d][4 * g + 2] * mul, acc[d][4 * g + 3] * mul)};
+      *reinterpret_cast<u32x2*>(row_ptr + 32 * d + 8 * g + 4 * hh) = w;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Forward (MODE 0) and the dQ half of the backward (MODE 1): a wave owns 32 queries, K and V stream
+// through LDS in blocks of 64 keys.
+template <int MODE>
+__global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
+  __shared__ __align__(16) bf16_t Kr[AT_BLK * AT_PR];                       // K by rows (S^T = K Q^T)
+  __shared__ __align__(16) bf16_t Xt[AT_BLK * AT_PT];                       // forward: V, backward: K, transposed reads
+  __shared__ __align__(16) bf16_t Vr[MODE == 1 ? AT_BLK * AT_PR : 8];       // backward: V by rows (dP^T = V dO^T)
+  __shared__ __align__(16) float Bias[AT_BLK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  const int N = a.N, b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * AT_OWN + wave * 32;
+  const bool active = q0 < N;  // wave-uniform
+  const size_t bo_qkv = (size_t)b * N * a.ld_qkv + (size_t)h * AT_DH;
+  const size_t bo_o = (size_t)b * N * a.ld_o + (size_t)h * AT_DH;
+  const bf16_t* kbase = a.k + bo_qkv;
+  const bf16_t* vbase = a.v + bo_qkv;
+  const float c2 = a.scale * AT_LOG2E;
+  const int qrow = min(q0 + j, N - 1);
+
+  bf16x8 qf[4], dof[4];
+  float l2 = 0.f, dsum = 0.f;
+  {
+    const bf16_t* p = a.q + bo_qkv + (size_t)qrow * a.ld_qkv + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = as_frag(*reinterpret_cast<const u32x4*>(p + 16 * ks));
+    if constexpr (MODE == 1) {
+      const bf16_t* pd = a.dout + bo_o + (size_t)qrow * a.ld_o + 8 * hh;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dof[ks] = as_frag(*reinterpret_cast<const u32x4*>(pd + 16 * ks));
+      l2 = a.lse[((size_t)b * a.H + h) * N + qrow];
+    }
+  }
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+
+  Stage sk, sv;
+  float breg = 0.f;
+  auto issue = [&](int kb) {
+    sk.issue(kbase, a.ld_qkv, kb * AT_BLK, N, tid);
+    sv.issue(vbase, a.ld_qkv, kb * AT_BLK, N, tid);
+    if (tid < AT_BLK) {
+      const int key = kb * AT_BLK + tid;
+      breg = 0.f;
+      if (a.key_bias != nullptr) breg = fmaxf(a.key_bias[(size_t)b * N + min(key, N - 1)], AT_MIN_BIAS) * AT_LOG2E;
+      if (key >= N) breg = -INFINITY;
+    }
+  };
+  auto commit = [&]() {
+    sk.commit(Kr, AT_PR, tid);
+    if constexpr (MODE == 0) {
+      sv.commit(Xt, AT_PT, tid);
+    } else {
+      sk.commit(Xt, AT_PT, tid);
+      sv.commit(Vr, AT_PR, tid);
+    }
+    if (tid < AT_BLK) Bias[tid] = breg;
+  };
+
+  const int nblk = (N + AT_BLK - 1) / AT_BLK;
+  // one pass over the keys: body(sub-block) runs on every 32-key sub-block that holds a key
+  auto stream_keys = [&](auto&& body) {
+    issue(0);
+    commit();
+    __syncthreads();
+    for (int kb = 0; kb < nblk; ++kb) {
+      if (kb + 1 < nblk) issue(kb + 1);
+      if (active) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+          if (kb * AT_BLK + sb * 32 >= N) break;
+          body(sb);
+        }
+      }
+      __syncthreads();
+      if (kb + 1 < nblk) {
+        commit();
+        __syncthreads();
+      }
+    }
+  };
+  // scaled, biased scores of a sub-block in the base-2 domain (rows = keys, lane column = the query)
+  auto scores = [&](int sb) -> f32x16 {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 kf = as_frag(*reinterpret_cast<const u32x4*>(&Kr[(sb * 32 + j) * AT_PR + 16 * ks + 8 * hh]));
+      s = mfma16(kf, qf[ks], s);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(&Bias[sb * 32 + 8 * g + 4 * hh]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[4 * g + e] = s[4 * g + e] * c2 + bv[e];
+    }
+    return s;
+  };
+  auto second_product = [&](int sb, const f32x16& w) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bf16x8 pb = pack8(w, t);
+#pragma unroll
+      for (int d = 0; d < 2; ++d) acc[d] = mfma16(tr_rows(Xt, sb * 32 + 16 * t, 32 * d, lane), pb, acc[d]);
+    }
+  };
+
+  if constexpr (MODE == 0) {
+    stream_keys([&](int sb) {
+      f32x16 s = scores(sb);
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, xchg32(mx));
+      const float mn = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      m = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f(s[r] - mn);
+        ps += s[r];
+      }
+      lsum = lsum * alpha + ps;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+      second_product(sb, s);
+    });
+  } else {
+    auto dprobs = [&](int sb) -> f32x16 {
+      f32x16 dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 vf = as_frag(*reinterpret_cast<const u32x4*>(&Vr[(sb * 32 + j) * AT_PR + 16 * ks + 8 * hh]));
+        dp = mfma16(vf, dof[ks], dp);
+      }
+      return dp;
+    };
+    // Pass 1: the softmax-backward row term sum_m p[n,m] dp[n,m], from the very probabilities and dp of
+    // pass 2.  (rowsum(dO * O) equals it in exact arithmetic, but O is stored rounded to bf16 and the
+    // difference does not cancel in sum_m ds[n,m] k_m: it shows up as an error of dq proportional to |dO||O|.)
+    float dacc = 0.f;
+    stream_keys([&](int sb) {
+      const f32x16 s = scores(sb);
+      const f32x16 dp = dprobs(sb);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dacc += __builtin_amdgcn_exp2f(s[r] - l2) * dp[r];
+    });
+    dsum = dacc + xchg32(dacc);
+    if (active && hh == 0 && q0 + j < N) a.dvec[((size_t)b * a.H + h) * N + q0 + j] = dsum;
+    stream_keys([&](int sb) {
+      f32x16 s = scores(sb);
+      const f32x16 dp = dprobs(sb);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - l2) * (dp[r] - dsum);
+      second_product(sb, s);
+    });
+  }
+  if (!active || q0 + j >= N) return;
+  if constexpr (MODE == 0) {
+    lsum += xchg32(lsum);
+    store_owned(a.out + bo_o + (size_t)(q0 + j) * a.ld_o, acc, 1.f / lsum, hh);
+    if (hh == 0) a.lse[((size_t)b * a.H + h) * N + q0 + j] = m + __builtin_amdgcn_logf(lsum);
+  } else {
+    store_owned(a.dq + (size_t)b * N * a.ld_d + (size_t)h * AT_DH + (size_t)(q0 + j) * a.ld_d, acc, a.scale, hh);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// dK / dV: a wave owns 32 keys, Q and dO stream through LDS in blocks of 64 queries.
+__global__ __launch_bounds__(256) void attn_kv_kernel(const AttnArgs a) {
+  __shared__ __align__(16) bf16_t Qr[AT_BLK * AT_PR];
+  __shared__ __align__(16) bf16_t Qt[AT_BLK * AT_PT];
+  __shared__ __align__(16) bf16_t Dr[AT_BLK * AT_PR];
+  __shared__ __align__(16) bf16_t Dt[AT_BLK * AT_PT];
+  __shared__ __align__(16) float L2s[AT_BLK];
+  __shared__ __align__(16) float Ds[AT_BLK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  const int N = a.N, b = blockIdx.z, h = blockIdx.y;
+  const int k0 = blockIdx.x * AT_OWN + wave * 32;
+  const bool active = k0 < N;
+  const size_t bo_qkv = (size_t)b * N * a.ld_qkv + (size_t)h * AT_DH;
+  const size_t bo_o = (size_t)b * N * a.ld_o + (size_t)h * AT_DH;
+  const bf16_t* qbase = a.q + bo_qkv;
+  const bf16_t* dbase = a.dout + bo_o;
+  const float* lbase = a.lse + ((size_t)b * a.H + h) * N;
+  const float* vbase = a.dvec + ((size_t)b * a.H + h) * N;
+  const float c2 = a.scale * AT_LOG2E;
+  const int krow = min(k0 + j, N - 1);
+
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16_t* pk = a.k + bo_qkv + (size_t)krow * a.ld_qkv + 8 * hh;
+    const bf16_t* pv = a.v + bo_qkv + (size_t)krow * a.ld_qkv + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = as_frag(*reinterpret_cast<const u32x4*>(pk + 16 * ks));
+      vf[ks] = as_frag(*reinterpret_cast<const u32x4*>(pv + 16 * ks));
+    }
+  }
+  float kbias = 0.f;
+  if (a.key_bias != nullptr) kbias = fmaxf(a.key_bias[(size_t)b * N + krow], AT_MIN_BIAS) * AT_LOG2E;
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[d][r] = dv[d][r] = 0.f;
+
+  Stage sq, sd;
+  float lreg = 0.f, dreg = 0.f;
+  auto issue = [&](int qb) {
+    sq.issue(qbase, a.ld_qkv, qb * AT_BLK, N, tid);
+    sd.issue(dbase, a.ld_o, qb * AT_BLK, N, tid);
+    if (tid < AT_BLK) {
+      const int q = qb * AT_BLK + tid;
+      lreg = q < N ? lbase[q] : INFINITY;  // exp2(x - inf) = 0: rows past the end contribute nothing
+      dreg = q < N ? vbase[q] : 0.f;
+    }
+  };
+  auto commit = [&]() {
+    sq.commit(Qr, AT_PR, tid);
+    sq.commit(Qt, AT_PT, tid);
+    sd.commit(Dr, AT_PR, tid);
+    sd.commit(Dt, AT_PT, tid);
+    if (tid < AT_BLK) { L2s[tid] = lreg; Ds[tid] = dreg; }
+  };
+
+  const int nblk = (N + AT_BLK - 1) / AT_BLK;
+  issue(0);
+  commit();
+  __syncthreads();
+  for (int qb = 0; qb < nblk; ++qb) {
+    if (qb + 1 < nblk) issue(qb + 1);
+    if (active) {
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        if (qb * AT_BLK + sb * 32 >= N) break;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 qa = as_frag(*reinterpret_cast<const u32x4*>(&Qr[(sb * 32 + j) * AT_PR + 16 * ks + 8 * hh]));
+          const bf16x8 da = as_frag(*reinterpret_cast<const u32x4*>(&Dr[(sb * 32 + j) * AT_PR + 16 * ks + 8 * hh]));
+          s = mfma16(qa, kf[ks], s);
+          dp = mfma16(da, vf[ks], dp);
+        }
+        // s, dp: rows = queries of the sub-block, lane column = the owned key
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 lv = *reinterpret_cast<const f32x4*>(&L2s[sb * 32 + 8 * g + 4 * hh]);
+          const f32x4 dvv = *reinterpret_cast<const f32x4*>(&Ds[sb * 32 + 8 * g + 4 * hh]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p = __builtin_amdgcn_exp2f(s[4 * g + e] * c2 + kbias - lv[e]);
+            s[4 * g + e] = p;
+            dp[4 * g + e] = p * (dp[4 * g + e] - dvv[e]);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bf16x8 pb = pack8(s, t), db = pack8(dp, t);
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            dv[d] = mfma16(tr_rows(Dt, sb * 32 + 16 * t, 32 * d, lane), pb, dv[d]);
+            dk[d] = mfma16(tr_rows(Qt, sb * 32 + 16 * t, 32 * d, lane), db, dk[d]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (qb + 1 < nblk) {
+      commit();
+      __syncthreads();
+    }
+  }
+  if (!active || k0 + j >= N) return;
+  const size_t off = (size_t)b * N * a.ld_d + (size_t)h * AT_DH + (size_t)(k0 + j) * a.ld_d;
+  store_owned(a.dk + off, dk, a.scale, hh);
+  store_owned(a.dv + off, dv, 1.f, hh);
+}
+
+// ----------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension with an optional residual add in front:
+//   s = x (+ r);  y = (s - mean(s)) * rstd(s) * gamma + beta.
+// One wave per row, the row stays in registers (D <= 512 * NCH).
+template <bool BF16, int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* x, const void* r, const float* gamma, const float* beta,
+                                                            long rows, int D, float eps, void* s_out, void* y,
+                                                            float* mean, float* rstd) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t base = (size_t)row * D;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+      load8<BF16>(x, base + col, v[c]);
+      if (r != nullptr) {
+        float t[8];
+        load8<BF16>(r, base + col, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[c][e] += t[e];
+        if constexpr (BF16) {
+          // the sum is what the next layer sees: round it once, normalise the rounded value
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[c][e] = bf16_to_f32(f32_to_bf16(v[c][e]));
+        }
+      }
+      if (s_out != nullptr) store8<BF16>(s_out, base + col, v[c]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[c][e];
+    }
+  }
+  const float mu = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mu; sq += d * d; }
+    }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+      float g[8], bt[8], o[8];
+      load8<false>(gamma, col, g);
+      load8<false>(beta, col, bt);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mu) * rs * g[e] + bt[e];
+      store8<BF16>(y, base + col, o);
+    }
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)) (+ ds_in);  dgamma += sum dy*xhat, dbeta += sum dy.
+// A workgroup takes LN_ROWS consecutive rows (one wave per row at a time) and adds its column
+// sums to dgamma / dbeta (f32, zeroed by the caller) with one atomic per column.
+constexpr int LN_ROWS = 32;
+template <bool BF16, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, const void* s, const float* gamma,
+                                                            const float* mean, const float* rstd, const void* ds_in,
+                                                            long rows, int D, void* dx, float* dgamma, float* dbeta) {
+  extern __shared__ float red[];  // [3][2][NCH*512]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[NCH][8], ab[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ag[c][e] = ab[c][e] = 0.f;
+  float g[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) load8<false>(gamma, col, g[c]);
+  }
+  const long row_end = min(rows, ((long)blockIdx.x + 1) * LN_ROWS);
+  for (long row = (long)blockIdx.x * LN_ROWS + wave; row < row_end; row += 4) {
+    const size_t base = (size_t)row * D;
+    const float mu = mean[row], rs = rstd[row];
+    float dyv[NCH][8], xh[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < D) {
+        load8<BF16>(dy, base + col, dyv[c]);
+        load8<BF16>(s, base + col, xh[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[c][e] = (xh[c][e] - mu) * rs;
+          ag[c][e] += dyv[c][e] * xh[c][e];
+          ab[c][e] += dyv[c][e];
+          dyv[c][e] *= g[c][e];
+          s1 += dyv[c][e];
+          s2 += dyv[c][e] * xh[c][e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < D) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rs * (dyv[c][e] - s1 - xh[c][e] * s2);
+        if (ds_in != nullptr) {
+          float t[8];
+          load8<BF16>(ds_in, base + col, t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += t[e];
+        }
+        store8<BF16>(dx, base + col, o);
+      }
+    }
+  }
+  // fold the four waves, then one atomic per column
+  const int DP = NCH * 512;
+  if (wave > 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[((wave - 1) * 2 + 0) * DP + (c * 64 + lane) * 8 + e] = ag[c][e];
+        red[((wave - 1) * 2 + 1) * DP + (c * 64 + lane) * 8 + e] = ab[c][e];
+      }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < D) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float sg = ag[c][e], sb = ab[c][e];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) {
+            sg += red[(w * 2 + 0) * DP + col + e];
+            sb += red[(w * 2 + 1) * DP + col + e];
+          }
+          atomicAdd(&dgamma[col + e], sg);
+          atomicAdd(&dbeta[col + e], sb);
+        }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// GELU, exact form: y = x * Phi(x), dy/dx = Phi(x) + x * phi(x).
+template <bool BF16, bool BWD>
+__global__ __launch_bounds__(256) void gelu_kernel(const void* x, const void* dy, size_t n8, void* out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  float v[8], o[8];
+  load8<BF16>(x, i * 8, v);
+  if constexpr (BWD) {
+    float d[8];
+    load8<BF16>(dy, i * 8, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float cdf = 0.5f * (1.f + erff(v[e] * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * v[e] * v[e]);
+      o[e] = d[e] * (cdf + v[e] * pdf);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+  }
+  store8<BF16>(out, i * 8, o);
+}
+
+int attn_check(const void* q, const void* k, const void* v, long ld_qkv, long ld_o, int B, int H, int N, int dh) {
+  VQAF_REQUIRE(q && k && v, VQAF_E_NULL);
+  VQAF_REQUIRE(B > 0 && H > 0 && N > 0 && B <= 65535 && H <= 65535, VQAF_E_SHAPE);
+  VQAF_REQUIRE(dh == AT_DH, VQAF_E_SHAPE);
+  VQAF_REQUIRE(ld_qkv >= (long)H * dh && ld_o >= (long)H * dh, VQAF_E_SHAPE);
+  VQAF_REQUIRE(ld_qkv % 8 == 0 && ld_o % 8 == 0, VQAF_E_ALIGN);
+  VQAF_REQUIRE(vqaf_aligned16(q) && vqaf_aligned16(k) && vqaf_aligned16(v), VQAF_E_ALIGN);
+  return VQAF_OK;
+}
+
+}  // namespace
+
+extern "C" int vqaf_attn_fwd(const void* q, const void* k, const void* v, long ld_qkv, const float* key_bias,
+                             int B, int H, int N, int dh, float scale, void* out, long ld_o, float* lse,
+                             vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  const int rc = attn_check(q, k, v, ld_qkv, ld_o, B, H, N, dh);
+  if (rc != VQAF_OK) return rc;
+  VQAF_REQUIRE(out && lse, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_aligned16(out), VQAF_E_ALIGN);
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
+  a.out = (bf16_t*)out; a.key_bias = key_bias; a.lse = lse;
+  a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.N = N; a.H = H; a.scale = scale;
+  const dim3 grid((N + AT_OWN - 1) / AT_OWN, H, B);
+  hipLaunchKernelGGL(attn_q_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_attn_bwd(const void* q, const void* k, const void* v, long ld_qkv, const float* key_bias,
+                             const void* dout, long ld_o, const float* lse, int B, int H, int N,
+                             int dh, float scale, void* dq, void* dk, void* dv, long ld_d, float* dvec,
+                             vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  const int rc = attn_check(q, k, v, ld_qkv, ld_o, B, H, N, dh);
+  if (rc != VQAF_OK) return rc;
+  VQAF_REQUIRE(dout && lse && dq && dk && dv && dvec, VQAF_E_NULL);
+  VQAF_REQUIRE(ld_d >= (long)H * dh, VQAF_E_SHAPE);
+  VQAF_REQUIRE(ld_d % 4 == 0, VQAF_E_ALIGN);
+  VQAF_REQUIRE(vqaf_aligned16(dout), VQAF_E_ALIGN);
+  VQAF_REQUIRE(((uintptr_t)dq & 7u) == 0 && ((uintptr_t)dk & 7u) == 0 && ((uintptr_t)dv & 7u) == 0, VQAF_E_ALIGN);
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
+  a.dout = (const bf16_t*)dout;
+  a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.key_bias = key_bias; a.lse = const_cast<float*>(lse); a.dvec = dvec;
+  a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.ld_d = ld_d; a.N = N; a.H = H; a.scale = scale;
+  const dim3 grid((N + AT_OWN - 1) / AT_OWN, H, B);
+  hipLaunchKernelGGL(attn_q_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);   // dQ, and the softmax row terms for the next launch
+  hipLaunchKernelGGL(attn_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  VQAF_LAUNCH_CHECK();
+}
+
+namespace {
+template <bool BF16>
+int launch_ln_fwd(int nch, const void* x, const void* r, const float* gamma, const float* beta, long rows, int D,
+                  float eps, void* s_out, void* y, float* mean, float* rstd, vqaf_stream_t stream) {
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define LN_FWD(NCH) hipLaunchKernelGGL((layernorm_fwd_kernel<BF16, NCH>), grid, dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, rows, D, eps, s_out, y, mean, rstd)
+  if (nch == 1) LN_FWD(1); else if (nch == 2) LN_FWD(2); else LN_FWD(4);
+#undef LN_FWD
+  return VQAF_OK;
+}
+template <bool BF16>
+int launch_ln_bwd(int nch, const void* dy, const void* s, const float* gamma, const float* mean, const float* rstd,
+                  const void* ds_in, long rows, int D, void* dx, float* dgamma, float* dbeta, vqaf_stream_t stream) {
+  const dim3 grid((unsigned)((rows + LN_ROWS - 1) / LN_ROWS));
+  const size_t lds = (size_t)3 * 2 * nch * 512 * sizeof(float);
+#define LN_BWD(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<BF16, NCH>), grid, dim3(256), lds, (hipStream_t)stream, dy, s, gamma, mean, rstd, ds_in, rows, D, dx, dgamma, dbeta)
+  if (nch == 1) LN_BWD(1); else if (nch == 2) LN_BWD(2); else LN_BWD(4);
+#undef LN_BWD
+  return VQAF_OK;
+}
+int ln_chunks(int D) { return D <= 512 ? 1 : D <= 1024 ? 2 : 4; }
+}  // namespace
+
+extern "C" int vqaf_layernorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long rows,
+                                  int D, float eps, int dtype, void* sum_out, void* y, float* mean, float* rstd,
+                                  vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(x && gamma && beta && y && mean && rstd, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(rows > 0 && D > 0 && D <= 2048 && D % 8 == 0 && (rows + 3) / 4 <= 0x7fffffffL, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_aligned16(x) && vqaf_aligned16(y) && vqaf_aligned16(gamma) && vqaf_aligned16(beta) &&
+                   (!residual || vqaf_aligned16(residual)) && (!sum_out || vqaf_aligned16(sum_out)), VQAF_E_ALIGN);
+  const int nch = ln_chunks(D);
+  if (dtype == VQAF_BF16) launch_ln_fwd<true>(nch, x, residual, gamma, beta, rows, D, eps, sum_out, y, mean, rstd, (hipStream_t)stream);
+  else launch_ln_fwd<false>(nch, x, residual, gamma, beta, rows, D, eps, sum_out, y, mean, rstd, (hipStream_t)stream);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_layernorm_bwd(const void* dy, const void* s, const float* gamma, const float* mean,
+                                  const float* rstd, const void* dsum_in, long rows, int D, int dtype, void* dx,
+                                  float* dgamma, float* dbeta, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(dy && s && gamma && mean && rstd && dx && dgamma && dbeta, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(rows > 0 && D > 0 && D <= 2048 && D % 8 == 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_aligned16(dy) && vqaf_aligned16(s) && vqaf_aligned16(dx) && vqaf_aligned16(gamma) &&
+                   (!dsum_in || vqaf_aligned16(dsum_in)), VQAF_E_ALIGN);
+  const int nch = ln_chunks(D);
+  if (dtype == VQAF_BF16) launch_ln_bwd<true>(nch, dy, s, gamma, mean, rstd, dsum_in, rows, D, dx, dgamma, dbeta, (hipStream_t)stream);
+  else launch_ln_bwd<false>(nch, dy, s, gamma, mean, rstd, dsum_in, rows, D, dx, dgamma, dbeta, (hipStream_t)stream);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_gelu_fwd(const void* x, size_t n, int dtype, void* y, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(x && y, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(n > 0 && n % 8 == 0 && n / 8 / 256 < 0x7fffffffUL, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_aligned16(x) && vqaf_aligned16(y), VQAF_E_ALIGN);
+  const size_t n8 = n / 8;
+  const dim3 grid((unsigned)((n8 + 255) / 256));
+  if (dtype == VQAF_BF16) hipLaunchKernelGGL((gelu_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, x, nullptr, n8, y);
+  else hipLaunchKernelGGL((gelu_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, x, nullptr, n8, y);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_gelu_bwd(const void* x, const void* dy, size_t n, int dtype, void* dx, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(x && dy && dx, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(n > 0 && n % 8 == 0 && n / 8 / 256 < 0x7fffffffUL, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_aligned16(x) && vqaf_aligned16(dy) && vqaf_aligned16(dx), VQAF_E_ALIGN);
+  const size_t n8 = n / 8;
+  const dim3 grid((unsigned)((n8 + 255) / 256));
+  if (dtype == VQAF_BF16) hipLaunchKernelGGL((gelu_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, n8, dx);
+  else hipLaunchKernelGGL((gelu_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, n8, dx);
+  VQAF_LAUNCH_CHECK();
+}

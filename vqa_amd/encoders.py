@@ -1,0 +1,526 @@
+"""Vision and text encoders behind the reference's encoder contract.
+
+The reference builds its encoders from Hugging Face models and projects them to the fusion width:
+`SwinTransformer` (model/vision_encoder.py:83-127) returns `(v_seq (B,N,512), v_global (B,512))`,
+`Bert` (model/text_encoder.py:14-48) returns `(q_seq (B,L,512), q_global (B,512))`; both expose
+`output_dim` and are passed to `VQAModel` as classes called with `out_features=` / `hidden_dim=`.
+
+Here the transformer stacks themselves are built on the HIP kernels of csrc/encoder.hip (attention,
+LayerNorm with the residual add, GELU); the Linear layers are plain library GEMMs.  `ViTModel` is a
+ViT-B/16-shaped stack (pre-LayerNorm blocks, CLS token, tanh pooler) and `BertModel` a BERT-base-shaped
+one (post-LayerNorm blocks, additive padding mask, tanh pooler).  Parameter names and shapes are those of
+the Hugging Face checkpoints of the two architectures (transformers 4.52, the version the reference pins:
+`encoder.layer.N.attention.attention.query.weight` for ViT, `encoder.layer.N.attention.self.query.weight`
+for BERT), so a checkpoint directory on the local disk loads without renaming (`load_checkpoint`).
+
+Activations are bf16 (the attention kernel is bf16 on MFMA with f32 accumulation); parameters may be f32
+(cast per use) or bf16.  There is no CPU path: the kernels raise on CPU tensors.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ._lib import check, dtype_code, load, ptr, stream_ptr
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd wrappers of the kernels
+# --------------------------------------------------------------------------------------------------
+class _SelfAttention(torch.autograd.Function):
+    """ctx (B,N,E) <- packed qkv (B,N,3E) bf16: softmax(q k^T / sqrt(dh) + key_bias) v per head."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_bias, heads):
+        B, N, E3 = qkv.shape
+        E = E3 // 3
+        if qkv.dtype != torch.bfloat16:
+            raise TypeError("the attention kernel computes in bf16; cast the encoder's activations to bfloat16")
+        if E % heads != 0 or E // heads != 64:
+            raise ValueError(f"the attention kernel supports head size 64, got {E}/{heads}")
+        qkv = qkv.contiguous()
+        kb = None if key_bias is None else key_bias.to(torch.float32).contiguous()
+        out = torch.empty(B, N, E, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
+        base = ptr(qkv)
+        check(load().vqaf_attn_fwd(base, base + 2 * E, base + 4 * E, E3, ptr(kb), B, heads, N, 64, 1.0 / 8.0,
+                                   ptr(out), E, ptr(lse), stream_ptr(qkv.device)), "vqaf_attn_fwd")
+        ctx.save_for_backward(qkv, lse, kb if kb is not None else lse.new_empty(0))
+        ctx.heads = heads
+        ctx.has_bias = kb is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        qkv, lse, kb = ctx.saved_tensors
+        B, N, E3 = qkv.shape
+        E = E3 // 3
+        g = grad_out.contiguous()
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        dqkv = torch.empty_like(qkv)
+        dvec = torch.empty_like(lse)
+        base, dbase = ptr(qkv), ptr(dqkv)
+        check(load().vqaf_attn_bwd(base, base + 2 * E, base + 4 * E, E3, ptr(kb) if ctx.has_bias else None,
+                                   ptr(g), E, ptr(lse), B, ctx.heads, N, 64, 1.0 / 8.0,
+                                   dbase, dbase + 2 * E, dbase + 4 * E, E3, ptr(dvec), stream_ptr(qkv.device)),
+              "vqaf_attn_bwd")
+        return dqkv, None, None
+
+
+def self_attention(qkv: torch.Tensor, key_bias: torch.Tensor | None, heads: int) -> torch.Tensor:
+    return _SelfAttention.apply(qkv, key_bias, heads)
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """(y, s) with s = x + residual (or x), y = LayerNorm(s) * weight + bias over the last dimension."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps):
+        D = x.shape[-1]
+        xc = x.contiguous()
+        rc = None if residual is None else residual.to(x.dtype).contiguous()
+        rows = xc.numel() // D
+        g = weight.detach().to(torch.float32).contiguous()
+        b = bias.detach().to(torch.float32).contiguous()
+        y = torch.empty_like(xc)
+        s = torch.empty_like(xc) if rc is not None else xc
+        stats = torch.empty(2, rows, dtype=torch.float32, device=x.device)
+        check(load().vqaf_layernorm_fwd(ptr(xc), ptr(rc), ptr(g), ptr(b), rows, D, float(eps), dtype_code(xc),
+                                        ptr(s) if rc is not None else None, ptr(y), ptr(stats[0]), ptr(stats[1]),
+                                        stream_ptr(x.device)), "vqaf_layernorm_fwd")
+        ctx.save_for_backward(s, g, stats)
+        ctx.has_res = rc is not None
+        ctx.wdtype = weight.dtype
+        ctx.set_materialize_grads(False)
+        return (y, s) if rc is not None else y
+
+    @staticmethod
+    def backward(ctx, gy, gs=None):
+        s, g, stats = ctx.saved_tensors
+        D = s.shape[-1]
+        rows = s.numel() // D
+        if gy is None:  # only the sum was used downstream
+            return gs, (gs if ctx.has_res else None), None, None, None
+        gy = gy.to(s.dtype).contiguous()
+        gsc = None if gs is None else gs.to(s.dtype).contiguous()
+        dx = torch.empty_like(s)
+        dgb = torch.zeros(2, D, dtype=torch.float32, device=s.device)
+        check(load().vqaf_layernorm_bwd(ptr(gy), ptr(s), ptr(g), ptr(stats[0]), ptr(stats[1]), ptr(gsc), rows, D,
+                                        dtype_code(s), ptr(dx), ptr(dgb[0]), ptr(dgb[1]), stream_ptr(s.device)),
+              "vqaf_layernorm_bwd")
+        return dx, (dx if ctx.has_res else None), dgb[0].to(ctx.wdtype), dgb[1].to(ctx.wdtype), None
+
+
+def add_layer_norm(x, residual, weight, bias, eps):
+    """Returns (LayerNorm(x + residual), x + residual); residual may be None (then the second item is x)."""
+    if residual is None:
+        return _AddLayerNorm.apply(x, None, weight, bias, eps), x
+    return _AddLayerNorm.apply(x, residual, weight, bias, eps)
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        check(load().vqaf_gelu_fwd(ptr(xc), xc.numel(), dtype_code(xc), ptr(y), stream_ptr(x.device)), "vqaf_gelu_fwd")
+        ctx.save_for_backward(xc)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xc,) = ctx.saved_tensors
+        gy = gy.to(xc.dtype).contiguous()
+        dx = torch.empty_like(xc)
+        check(load().vqaf_gelu_bwd(ptr(xc), ptr(gy), xc.numel(), dtype_code(xc), ptr(dx), stream_ptr(xc.device)),
+              "vqaf_gelu_bwd")
+        return dx
+
+
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    return _Gelu.apply(x)
+
+
+def _linear(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
+    w, b = lin.weight, lin.bias
+    if w.dtype != x.dtype:
+        w = w.to(x.dtype)
+        b = None if b is None else b.to(x.dtype)
+    return F.linear(x, w, b)
+
+
+def _packed_qkv(x, q: nn.Linear, k: nn.Linear, v: nn.Linear) -> torch.Tensor:
+    """One GEMM for the three projections (the checkpoint keeps them as three Linear layers)."""
+    w = torch.cat([q.weight, k.weight, v.weight], 0)
+    b = torch.cat([q.bias, k.bias, v.bias], 0)
+    if w.dtype != x.dtype:
+        w, b = w.to(x.dtype), b.to(x.dtype)
+    return F.linear(x, w, b)
+
+
+# --------------------------------------------------------------------------------------------------
+# configs
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class ViTConfig:
+    """google/vit-base-patch16-224 shape by default; image_size=384 gives 577 tokens."""
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    image_size: int = 224
+    patch_size: int = 16
+    num_channels: int = 3
+    layer_norm_eps: float = 1e-12
+    hidden_dropout_prob: float = 0.0
+    initializer_range: float = 0.02
+
+
+@dataclass
+class BertConfig:
+    """bert-base-uncased shape by default."""
+    vocab_size: int = 30522
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 2
+    layer_norm_eps: float = 1e-12
+    hidden_dropout_prob: float = 0.1
+    pad_token_id: int = 0
+    initializer_range: float = 0.02
+
+
+def _config_from_json(cls, path):
+    with open(path) as f:
+        raw = json.load(f)
+    fields = {k: raw[k] for k in cls.__dataclass_fields__ if k in raw}
+    return cls(**fields)
+
+
+def _init_weights(module: nn.Module, std: float) -> None:
+    for m in module.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=std)
+            nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.Embedding):
+            nn.init.normal_(m.weight, std=std)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+
+# --------------------------------------------------------------------------------------------------
+# ViT
+# --------------------------------------------------------------------------------------------------
+class _Named(nn.Module):
+    """A module that only groups children under a checkpoint name."""
+
+
+class _ViTPatchEmbeddings(nn.Module):
+    def __init__(self, cfg: ViTConfig):
+        super().__init__()
+        self.projection = nn.Conv2d(cfg.num_channels, cfg.hidden_size, cfg.patch_size, stride=cfg.patch_size)
+        self.patch = cfg.patch_size
+
+    def forward(self, images):
+        # non-overlapping patches: the strided convolution is one GEMM over (B*gh*gw, C*P*P) patch rows
+        B, C, Hh, Ww = images.shape
+        P = self.patch
+        gh, gw = Hh // P, Ww // P
+        rows = images.reshape(B, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * P * P)
+        w = self.projection.weight.reshape(self.projection.weight.shape[0], -1)
+        b = self.projection.bias
+        if w.dtype != rows.dtype:
+            w, b = w.to(rows.dtype), b.to(rows.dtype)
+        return F.linear(rows, w, b)
+
+
+class _ViTEmbeddings(nn.Module):
+    def __init__(self, cfg: ViTConfig):
+        super().__init__()
+        n = (cfg.image_size // cfg.patch_size) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, cfg.hidden_size))
+        self.position_embeddings = nn.Parameter(torch.zeros(1, n + 1, cfg.hidden_size))
+        self.patch_embeddings = _ViTPatchEmbeddings(cfg)
+        nn.init.trunc_normal_(self.cls_token, std=cfg.initializer_range)
+        nn.init.trunc_normal_(self.position_embeddings, std=cfg.initializer_range)
+        self.p = cfg.hidden_dropout_prob
+
+    def forward(self, images):
+        x = self.patch_embeddings(images)
+        B = x.shape[0]
+        if x.shape[1] + 1 != self.position_embeddings.shape[1]:
+            raise ValueError(f"{x.shape[1]} patches but {self.position_embeddings.shape[1] - 1} position embeddings: "
+                             "build the encoder with the image size it is fed (no position interpolation)")
+        x = torch.cat([self.cls_token.to(x.dtype).expand(B, -1, -1), x], 1) + self.position_embeddings.to(x.dtype)
+        return F.dropout(x, self.p, self.training)
+
+
+class _ViTSelfAttention(nn.Module):
+    def __init__(self, E):
+        super().__init__()
+        self.query, self.key, self.value = nn.Linear(E, E), nn.Linear(E, E), nn.Linear(E, E)
+
+
+class _Dense(nn.Module):
+    def __init__(self, i, o):
+        super().__init__()
+        self.dense = nn.Linear(i, o)
+
+
+class _ViTAttention(nn.Module):
+    def __init__(self, E):
+        super().__init__()
+        self.attention = _ViTSelfAttention(E)
+        self.output = _Dense(E, E)
+
+
+class _ViTLayer(nn.Module):
+    def __init__(self, cfg: ViTConfig):
+        super().__init__()
+        E = cfg.hidden_size
+        self.attention = _ViTAttention(E)
+        self.intermediate = _Dense(E, cfg.intermediate_size)
+        self.output = _Dense(cfg.intermediate_size, E)
+        self.layernorm_before = nn.LayerNorm(E, eps=cfg.layer_norm_eps)
+        self.layernorm_after = nn.LayerNorm(E, eps=cfg.layer_norm_eps)
+        self.heads, self.eps, self.p = cfg.num_attention_heads, cfg.layer_norm_eps, cfg.hidden_dropout_prob
+
+    def forward(self, y, s):
+        """y = layernorm_before(s) of this layer; returns (layernorm of the NEXT consumer's input, stream)
+        as a pair so that every residual add runs inside the LayerNorm kernel that follows it."""
+        a = self.attention.attention
+        ctx = self_attention(_packed_qkv(y, a.query, a.key, a.value), None, self.heads)
+        att = F.dropout(_linear(ctx, self.attention.output.dense), self.p, self.training)
+        y2, s2 = add_layer_norm(att, s, self.layernorm_after.weight, self.layernorm_after.bias, self.eps)
+        h = gelu(_linear(y2, self.intermediate.dense))
+        o = F.dropout(_linear(h, self.output.dense), self.p, self.training)
+        return o, s2
+
+
+class _Layers(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.layer = nn.ModuleList(layers)
+
+
+class _Pooler(nn.Module):
+    def __init__(self, E):
+        super().__init__()
+        self.dense = nn.Linear(E, E)
+
+    def forward(self, x):
+        return torch.tanh(_linear(x[:, 0], self.dense))
+
+
+class ViTModel(nn.Module):
+    """`last_hidden_state (B, N+1, E), pooler_output (B, E)` of a ViT with the layout of
+    google/vit-base-patch16-224 (pre-LayerNorm blocks; final LayerNorm; pooler = tanh(dense(CLS)))."""
+
+    def __init__(self, config: ViTConfig | None = None, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.config = cfg = config or ViTConfig()
+        self.compute_dtype = compute_dtype
+        self.embeddings = _ViTEmbeddings(cfg)
+        self.encoder = _Layers([_ViTLayer(cfg) for _ in range(cfg.num_hidden_layers)])
+        self.layernorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.pooler = _Pooler(cfg.hidden_size)
+        _init_weights(self, cfg.initializer_range)
+
+    def forward(self, pixel_values):
+        x = self.embeddings(pixel_values.to(self.compute_dtype))
+        # block i:  s <- s + attn(LN1_i(s));  s <- s + mlp(LN2_i(s)).  Each add is done by the LayerNorm kernel
+        # that consumes the sum, so the loop carries (pending branch output, stream before the add).
+        pending, s = None, x
+        for lyr in self.encoder.layer:
+            y, s = add_layer_norm(s if pending is None else pending, None if pending is None else s,
+                                  lyr.layernorm_before.weight, lyr.layernorm_before.bias, lyr.eps)
+            pending, s = lyr(y, s)
+        h, _ = add_layer_norm(pending, s, self.layernorm.weight, self.layernorm.bias, self.config.layer_norm_eps)
+        return h, self.pooler(h)
+
+
+# --------------------------------------------------------------------------------------------------
+# BERT
+# --------------------------------------------------------------------------------------------------
+class _BertEmbeddings(nn.Module):
+    def __init__(self, cfg: BertConfig):
+        super().__init__()
+        E = cfg.hidden_size
+        self.word_embeddings = nn.Embedding(cfg.vocab_size, E, padding_idx=cfg.pad_token_id)
+        self.position_embeddings = nn.Embedding(cfg.max_position_embeddings, E)
+        self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, E)
+        self.LayerNorm = nn.LayerNorm(E, eps=cfg.layer_norm_eps)
+        self.eps, self.p = cfg.layer_norm_eps, cfg.hidden_dropout_prob
+
+    def forward(self, input_ids, dtype):
+        L = input_ids.shape[1]
+        pos = self.position_embeddings.weight[:L] + self.token_type_embeddings.weight[0]
+        x = (self.word_embeddings(input_ids) + pos).to(dtype)
+        y, _ = add_layer_norm(x, None, self.LayerNorm.weight, self.LayerNorm.bias, self.eps)
+        return F.dropout(y, self.p, self.training)
+
+
+class _BertSelfAttention(nn.Module):
+    def __init__(self, E):
+        super().__init__()
+        self.query, self.key, self.value = nn.Linear(E, E), nn.Linear(E, E), nn.Linear(E, E)
+
+
+class _BertSelfOutput(nn.Module):
+    def __init__(self, i, o, eps):
+        super().__init__()
+        self.dense = nn.Linear(i, o)
+        self.LayerNorm = nn.LayerNorm(o, eps=eps)
+
+
+class _BertAttention(nn.Module):
+    def __init__(self, E, eps):
+        super().__init__()
+        self.self = _BertSelfAttention(E)
+        self.output = _BertSelfOutput(E, E, eps)
+
+
+class _BertLayer(nn.Module):
+    def __init__(self, cfg: BertConfig):
+        super().__init__()
+        E = cfg.hidden_size
+        self.attention = _BertAttention(E, cfg.layer_norm_eps)
+        self.intermediate = _Dense(E, cfg.intermediate_size)
+        self.output = _BertSelfOutput(cfg.intermediate_size, E, cfg.layer_norm_eps)
+        self.heads, self.eps, self.p = cfg.num_attention_heads, cfg.layer_norm_eps, cfg.hidden_dropout_prob
+
+    def forward(self, x, key_bias):
+        a = self.attention.self
+        ctx = self_attention(_packed_qkv(x, a.query, a.key, a.value), key_bias, self.heads)
+        att = F.dropout(_linear(ctx, self.attention.output.dense), self.p, self.training)
+        ln = self.attention.output.LayerNorm
+        x1, _ = add_layer_norm(att, x, ln.weight, ln.bias, self.eps)
+        h = gelu(_linear(x1, self.intermediate.dense))
+        o = F.dropout(_linear(h, self.output.dense), self.p, self.training)
+        ln = self.output.LayerNorm
+        x2, _ = add_layer_norm(o, x1, ln.weight, ln.bias, self.eps)
+        return x2
+
+
+class BertModel(nn.Module):
+    """`last_hidden_state (B, L, E), pooler_output (B, E)` of a BERT encoder with the layout of
+    bert-base-uncased (post-LayerNorm blocks; absolute positions; token type 0)."""
+
+    def __init__(self, config: BertConfig | None = None, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.config = cfg = config or BertConfig()
+        self.compute_dtype = compute_dtype
+        self.embeddings = _BertEmbeddings(cfg)
+        self.encoder = _Layers([_BertLayer(cfg) for _ in range(cfg.num_hidden_layers)])
+        self.pooler = _Pooler(cfg.hidden_size)
+        _init_weights(self, cfg.initializer_range)
+
+    def forward(self, input_ids, attention_mask=None):
+        x = self.embeddings(input_ids, self.compute_dtype)
+        key_bias = None
+        if attention_mask is not None:
+            # the extended mask of BertModel: 0 where attended, a large negative number on padding
+            key_bias = (1.0 - attention_mask.to(torch.float32)) * -1.0e30
+        for lyr in self.encoder.layer:
+            x = lyr(x, key_bias)
+        return x, self.pooler(x)
+
+
+# --------------------------------------------------------------------------------------------------
+# checkpoints on the local disk
+# --------------------------------------------------------------------------------------------------
+def _read_state(path: str) -> dict:
+    """Tensors of a checkpoint directory or file: model.safetensors, or pytorch_model.bin read with
+    weights_only=True (nothing in the file is executed)."""
+    if os.path.isdir(path):
+        for name in ("model.safetensors", "pytorch_model.bin"):
+            if os.path.exists(os.path.join(path, name)):
+                path = os.path.join(path, name)
+                break
+        else:
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {path}")
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def load_checkpoint(model: nn.Module, path: str, prefixes=("vit.", "bert.")) -> nn.Module:
+    """Loads a locally stored Hugging Face checkpoint of the same architecture into `model`.
+    Task-head prefixes (`vit.`, `bert.`) are stripped; LayerNorm `gamma`/`beta` (old TF-converted BERT
+    files) are renamed; tensors the model does not have (`cls.*`, `classifier.*`, `position_ids`) are
+    ignored; a tensor the model has but the file lacks is an error."""
+    raw = _read_state(path)
+    own = model.state_dict()
+    state = {}
+    for k, v in raw.items():
+        for p in prefixes:
+            if k.startswith(p):
+                k = k[len(p):]
+                break
+        k = k.replace("LayerNorm.gamma", "LayerNorm.weight").replace("LayerNorm.beta", "LayerNorm.bias")
+        if k in own:
+            state[k] = v
+    missing = [k for k in own if k not in state]
+    if missing:
+        raise KeyError(f"checkpoint {path} lacks {len(missing)} tensors of the model, e.g. {missing[:3]}")
+    model.load_state_dict(state)
+    return model
+
+
+# --------------------------------------------------------------------------------------------------
+# the encoder classes VQAModel takes
+# --------------------------------------------------------------------------------------------------
+class ViT(nn.Module):
+    """Vision encoder with the reference's contract (model/vision_encoder.py:83-127):
+    `forward(images (B,3,S,S)) -> v_seq (B, N, out_features), v_global (B, out_features)` where the
+    sequence is every token of the last hidden state and the global feature is the pooler output."""
+
+    def __init__(self, model_name: str | None = None, out_features: int = 512, config: ViTConfig | None = None,
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        if model_name is not None and config is None and os.path.exists(os.path.join(model_name, "config.json")):
+            config = _config_from_json(ViTConfig, os.path.join(model_name, "config.json"))
+        self.vit = ViTModel(config, compute_dtype)
+        if model_name is not None:
+            load_checkpoint(self.vit, model_name)
+        E = self.vit.config.hidden_size
+        self.seq_projection = nn.Linear(E, out_features)
+        self.global_projection = nn.Linear(E, out_features)
+        self.output_dim = out_features
+
+    def forward(self, images):
+        h, pooled = self.vit(images)
+        return _linear(h, self.seq_projection), _linear(pooled, self.global_projection)
+
+
+class Bert(nn.Module):
+    """Text encoder with the reference's contract (model/text_encoder.py:14-48):
+    `forward(input_ids, attention_mask) -> q_seq (B, L, hidden_dim), q_global (B, hidden_dim)`.
+    `model_name` is a LOCAL checkpoint directory (there is no hub access); None = random init."""
+
+    def __init__(self, model_name: str | None = None, hidden_dim: int = 512, config: BertConfig | None = None,
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        if model_name is not None and config is None and os.path.exists(os.path.join(model_name, "config.json")):
+            config = _config_from_json(BertConfig, os.path.join(model_name, "config.json"))
+        self.bert = BertModel(config, compute_dtype)
+        if model_name is not None:
+            load_checkpoint(self.bert, model_name)
+        E = self.bert.config.hidden_size
+        self.seq_projection = nn.Linear(E, hidden_dim)
+        self.global_projection = nn.Linear(E, hidden_dim)
+        self.output_dim = hidden_dim
+
+    def forward(self, input_ids, attention_mask):
+        h, pooled = self.bert(input_ids, attention_mask)
+        return _linear(h, self.seq_projection), _linear(pooled, self.global_projection)
