@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the fp32 tier sub-measurement")
+    ap.add_argument("--no-full-model", action="store_true", help="skip the encoder + fusion forward/backward leg")
     ap.add_argument("--cpu-sample", type=int, default=64)
     return ap.parse_args()
 
@@ -282,6 +283,76 @@ def dense_leg(dev, dtype):
                              "token_bytes": nbytes, "samples/s": round(B / ms * 1e3, 1)}
         del graph
     return out
+
+
+def full_model_leg(dev):
+    """BASELINE configs[1]: the whole model (ViT-B/16 at 224 px + BERT-base at 30 tokens, CoAttention with
+    token pruning at keep ratio 0.5, the classifier), forward + backward, batch 64, bf16 parameters and
+    activations, non-private, random-init weights, synthetic inputs.  The GEMM flops counted are those of
+    the two encoder stacks (three GEMMs of 2*T*in*out per Linear over forward and backward, attention
+    4*T*N*E forward and 2.5x that backward)."""
+    from vqa_amd import encoders, ops
+    from vqa_amd import model as vqa_model
+    B, S, L, E, LAYERS, FF = 64, 224, N_TXT, 768, 12, 3072
+    torch.manual_seed(0)
+    m = vqa_model.VQAModel(encoders.ViT, encoders.Bert, fusion_type="co_attention", num_classes=C,
+                           use_token_pruning=True, prune_ratio=0.5).to(dev).to(torch.bfloat16).train()
+    gen = torch.Generator(device=dev).manual_seed(5)
+    imgs = torch.randn(B, 3, S, S, device=dev, generator=gen).to(torch.bfloat16)
+    ids = torch.randint(1, 30000, (B, L), device=dev, generator=gen)
+    mask = torch.ones(B, L, dtype=torch.long, device=dev)
+    y = torch.randint(0, C, (B,), device=dev, generator=gen)
+    params = [p for p in m.parameters()]
+
+    def fb():
+        for p in params:
+            p.grad = None
+        loss = ops.cross_entropy_mean(m(imgs, ids, mask), y)
+        loss.backward(gradient=ops.unit_gradient(loss))
+
+    for _ in range(3):
+        fb()
+    torch.cuda.synchronize()
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fb()
+    e1.record()
+    torch.cuda.synchronize()
+    ms_eager = e0.elapsed_time(e1) / reps
+    launch, graph = "eager", None
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fb()
+        for _ in range(2):
+            graph.replay()
+        torch.cuda.synchronize()
+        launch = "hipgraph"
+    except Exception as exc:  # capture is an optimisation of the launch path only
+        print(f"[bench] full-model leg: graph capture unavailable ({type(exc).__name__}: {exc}); eager", file=sys.stderr)
+        graph = None
+        torch.cuda.synchronize()
+    ms = ms_eager
+    if graph is not None:
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+    flops = 0.0
+    for T, N in ((B * ((S // 16) ** 2 + 1), (S // 16) ** 2 + 1), (B * L, L)):
+        gemm = 2.0 * T * (4 * E * E + 2 * E * FF) * LAYERS
+        attn = 4.0 * T * N * E * LAYERS
+        flops += 3.0 * gemm + 3.5 * attn
+    del graph
+    return {"workload": "ViT-B/16 (224 px) + BERT-base (30 tokens) + CoAttention keep 0.5 + classifier, fwd+bwd, "
+                        "batch 64, bf16, non-private, random init",
+            "ms_fwd_bwd": round(ms, 3), "ms_fwd_bwd_eager": round(ms_eager, 3), "launch": launch,
+            "samples/s": round(B / ms * 1e3, 1), "encoder_TFLOP/s": round(flops / ms / 1e9, 1),
+            "frac_of_2500_TFLOPs": round(flops / ms / 1e9 / 2500.0, 4)}
 
 
 def cpu_baseline(sample):
@@ -568,6 +639,8 @@ def main():
         if not args.no_sweep:
             line["prune_mix_cfg4"] = prune_mix_sweep(dev, dtype)
             line["dense_branch"] = dense_leg(dev, dtype)
+        if not args.no_full_model and dtype == torch.bfloat16:
+            line["full_model_cfg2"] = full_model_leg(dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(line), flush=True)

@@ -531,17 +531,20 @@ int vqaf_attn_bwd(const void* q, const void* k, const void* v, long ld_qkv, cons
 /* LayerNorm over the last dimension with the residual add in front of it (nn.LayerNorm of the
  * BertSelfOutput / BertOutput / ViTLayer blocks): s = x (+ residual), y = LN(s) * gamma + beta.
  * x, residual (may be NULL), sum_out (may be NULL; receives s), y: (rows, D) `dtype`; gamma, beta
- * (D) f32; mean, rstd (rows) f32 for the backward.  D <= 2048, D % 8 == 0. */
-int vqaf_layernorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long rows,
-                       int D, float eps, int dtype, void* sum_out, void* y, float* mean, float* rstd,
-                       vqaf_stream_t stream);
+ * (D) `param_dtype`; mean, rstd (rows) f32 for the backward.  D <= 2048, D % 8 == 0. */
+int vqaf_layernorm_fwd(const void* x, const void* residual, const void* gamma, const void* beta,
+                       int param_dtype, long rows, int D, float eps, int dtype, void* sum_out, void* y,
+                       float* mean, float* rstd, vqaf_stream_t stream);
 
 /* Backward: dx (rows, D) = LayerNorm backward of dy at input s (+ dsum_in, the gradient that reaches
- * s directly through a residual branch; may be NULL).  dgamma, dbeta (D) f32 are ACCUMULATED into
- * (atomics): the caller zeroes them. */
-int vqaf_layernorm_bwd(const void* dy, const void* s, const float* gamma, const float* mean,
-                       const float* rstd, const void* dsum_in, long rows, int D, int dtype, void* dx,
-                       float* dgamma, float* dbeta, vqaf_stream_t stream);
+ * s directly through a residual branch; may be NULL); dgamma, dbeta (D) `param_dtype` are written
+ * (fixed summation order).  workspace: vqaf_layernorm_bwd_workspace_bytes(rows, D) bytes of device
+ * memory, 16-byte aligned (per-workgroup column sums). */
+size_t vqaf_layernorm_bwd_workspace_bytes(long rows, int D);
+int vqaf_layernorm_bwd(const void* dy, const void* s, const void* gamma, int param_dtype,
+                       const float* mean, const float* rstd, const void* dsum_in, long rows, int D,
+                       int dtype, void* dx, void* dgamma, void* dbeta, void* workspace,
+                       size_t workspace_bytes, vqaf_stream_t stream);
 
 /* GELU in its exact (erf) form, the "gelu" activation of both encoder configs; n % 8 == 0. */
 int vqaf_gelu_fwd(const void* x, size_t n, int dtype, void* y, vqaf_stream_t stream);

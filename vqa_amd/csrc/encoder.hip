@@ -403,8 +403,8 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(const AttnArgs a) {
 // LayerNorm over the last dimension with an optional residual add in front:
 //   s = x (+ r);  y = (s - mean(s)) * rstd(s) * gamma + beta.
 // One wave per row, the row stays in registers (D <= 512 * NCH).
-template <bool BF16, int NCH>
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* x, const void* r, const float* gamma, const float* beta,
+template <bool BF16, bool PBF16, int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* x, const void* r, const void* gamma, const void* beta,
                                                             long rows, int D, float eps, void* s_out, void* y,
                                                             float* mean, float* rstd) {
   const int lane = threadIdx.x & 63;
@@ -450,8 +450,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* x, const
     const int col = (c * 64 + lane) * 8;
     if (col < D) {
       float g[8], bt[8], o[8];
-      load8<false>(gamma, col, g);
-      load8<false>(beta, col, bt);
+      load8<PBF16>(gamma, col, g);
+      load8<PBF16>(beta, col, bt);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mu) * rs * g[e] + bt[e];
       store8<BF16>(y, base + col, o);
@@ -460,14 +460,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* x, const
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)) (+ ds_in);  dgamma += sum dy*xhat, dbeta += sum dy.
-// A workgroup takes LN_ROWS consecutive rows (one wave per row at a time) and adds its column
-// sums to dgamma / dbeta (f32, zeroed by the caller) with one atomic per column.
+// dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)) (+ ds_in);  dgamma = sum dy*xhat, dbeta = sum dy.
+// A workgroup takes LN_ROWS consecutive rows (one wave per row at a time) and writes its column sums
+// to part[block][2][D]; layernorm_param_grad_kernel folds the blocks.  (Atomics onto the 2*D sums
+// were tried first: every workgroup hits the same addresses and the kernel ran at a fifth of its
+// memory-bound time.)
 constexpr int LN_ROWS = 32;
-template <bool BF16, int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, const void* s, const float* gamma,
+template <bool BF16, bool PBF16, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, const void* s, const void* gamma,
                                                             const float* mean, const float* rstd, const void* ds_in,
-                                                            long rows, int D, void* dx, float* dgamma, float* dbeta) {
+                                                            long rows, int D, void* dx, float* part) {
   extern __shared__ float red[];  // [3][2][NCH*512]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ag[NCH][8], ab[NCH][8];
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, cons
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = (c * 64 + lane) * 8;
-    if (col < D) load8<false>(gamma, col, g[c]);
+    if (col < D) load8<PBF16>(gamma, col, g[c]);
   }
   const long row_end = min(rows, ((long)blockIdx.x + 1) * LN_ROWS);
   for (long row = (long)blockIdx.x * LN_ROWS + wave; row < row_end; row += 4) {
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, cons
       }
     }
   }
-  // fold the four waves, then one atomic per column
+  // fold the four waves, then one store per column
   const int DP = NCH * 512;
   if (wave > 0) {
 #pragma unroll
@@ -536,23 +538,45 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, cons
   }
   __syncthreads();
   if (wave == 0) {
+    float* pg = part + (size_t)blockIdx.x * 2 * D;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = (c * 64 + lane) * 8;
       if (col < D) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float sg = ag[c][e], sb = ab[c][e];
 #pragma unroll
           for (int w = 0; w < 3; ++w) {
-            sg += red[(w * 2 + 0) * DP + col + e];
-            sb += red[(w * 2 + 1) * DP + col + e];
+            ag[c][e] += red[(w * 2 + 0) * DP + col + e];
+            ab[c][e] += red[(w * 2 + 1) * DP + col + e];
           }
-          atomicAdd(&dgamma[col + e], sg);
-          atomicAdd(&dbeta[col + e], sb);
         }
+        store8<false>(pg, col, ag[c]);
+        store8<false>(pg + D, col, ab[c]);
       }
     }
+  }
+}
+
+// dgamma, dbeta (D) <- part[nblk][2][D], in the parameters' dtype; fixed summation order.
+// A workgroup folds 16 columns: thread (q, c) adds blocks q, q+16, ... of column c.
+template <bool PBF16>
+__global__ __launch_bounds__(256) void layernorm_param_grad_kernel(const float* part, int nblk, int D, void* dgamma,
+                                                                   void* dbeta) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;  // column of the (2, D) pair, flattened
+  float acc = 0.f;
+  if (c < 2 * D)
+    for (int b = q; b < nblk; b += 16) acc += part[(size_t)b * 2 * D + c];
+  red[q][cl] = acc;
+  __syncthreads();
+  if (q == 0 && c < 2 * D) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += red[i][cl];
+    if (c < D) store1<PBF16>(dgamma, c, v);
+    else store1<PBF16>(dbeta, c - D, v);
   }
 }
 
@@ -634,55 +658,77 @@ extern "C" int vqaf_attn_bwd(const void* q, const void* k, const void* v, long l
 }
 
 namespace {
-template <bool BF16>
-int launch_ln_fwd(int nch, const void* x, const void* r, const float* gamma, const float* beta, long rows, int D,
-                  float eps, void* s_out, void* y, float* mean, float* rstd, vqaf_stream_t stream) {
+template <bool BF16, bool PBF16>
+void launch_ln_fwd(int nch, const void* x, const void* r, const void* gamma, const void* beta, long rows, int D,
+                   float eps, void* s_out, void* y, float* mean, float* rstd, hipStream_t stream) {
   const dim3 grid((unsigned)((rows + 3) / 4));
-#define LN_FWD(NCH) hipLaunchKernelGGL((layernorm_fwd_kernel<BF16, NCH>), grid, dim3(256), 0, (hipStream_t)stream, x, r, gamma, beta, rows, D, eps, s_out, y, mean, rstd)
+#define LN_FWD(NCH) hipLaunchKernelGGL((layernorm_fwd_kernel<BF16, PBF16, NCH>), grid, dim3(256), 0, stream, x, r, gamma, beta, rows, D, eps, s_out, y, mean, rstd)
   if (nch == 1) LN_FWD(1); else if (nch == 2) LN_FWD(2); else LN_FWD(4);
 #undef LN_FWD
-  return VQAF_OK;
 }
-template <bool BF16>
-int launch_ln_bwd(int nch, const void* dy, const void* s, const float* gamma, const float* mean, const float* rstd,
-                  const void* ds_in, long rows, int D, void* dx, float* dgamma, float* dbeta, vqaf_stream_t stream) {
+template <bool BF16, bool PBF16>
+void launch_ln_bwd(int nch, const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
+                   const void* ds_in, long rows, int D, void* dx, float* part, hipStream_t stream) {
   const dim3 grid((unsigned)((rows + LN_ROWS - 1) / LN_ROWS));
   const size_t lds = (size_t)3 * 2 * nch * 512 * sizeof(float);
-#define LN_BWD(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<BF16, NCH>), grid, dim3(256), lds, (hipStream_t)stream, dy, s, gamma, mean, rstd, ds_in, rows, D, dx, dgamma, dbeta)
+#define LN_BWD(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<BF16, PBF16, NCH>), grid, dim3(256), lds, stream, dy, s, gamma, mean, rstd, ds_in, rows, D, dx, part)
   if (nch == 1) LN_BWD(1); else if (nch == 2) LN_BWD(2); else LN_BWD(4);
 #undef LN_BWD
-  return VQAF_OK;
 }
 int ln_chunks(int D) { return D <= 512 ? 1 : D <= 1024 ? 2 : 4; }
 }  // namespace
 
-extern "C" int vqaf_layernorm_fwd(const void* x, const void* residual, const float* gamma, const float* beta, long rows,
-                                  int D, float eps, int dtype, void* sum_out, void* y, float* mean, float* rstd,
-                                  vqaf_stream_t stream) {
+extern "C" int vqaf_layernorm_fwd(const void* x, const void* residual, const void* gamma, const void* beta,
+                                  int param_dtype, long rows, int D, float eps, int dtype, void* sum_out, void* y,
+                                  float* mean, float* rstd, vqaf_stream_t stream) {
   VQAF_ENTRY();
   VQAF_REQUIRE(x && gamma && beta && y && mean && rstd, VQAF_E_NULL);
-  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(param_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(rows > 0 && D > 0 && D <= 2048 && D % 8 == 0 && (rows + 3) / 4 <= 0x7fffffffL, VQAF_E_SHAPE);
   VQAF_REQUIRE(vqaf_aligned16(x) && vqaf_aligned16(y) && vqaf_aligned16(gamma) && vqaf_aligned16(beta) &&
                    (!residual || vqaf_aligned16(residual)) && (!sum_out || vqaf_aligned16(sum_out)), VQAF_E_ALIGN);
   const int nch = ln_chunks(D);
-  if (dtype == VQAF_BF16) launch_ln_fwd<true>(nch, x, residual, gamma, beta, rows, D, eps, sum_out, y, mean, rstd, (hipStream_t)stream);
-  else launch_ln_fwd<false>(nch, x, residual, gamma, beta, rows, D, eps, sum_out, y, mean, rstd, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VQAF_BF16) {
+    if (param_dtype == VQAF_BF16) launch_ln_fwd<true, true>(nch, x, residual, gamma, beta, rows, D, eps, sum_out, y, mean, rstd, st);
+    else launch_ln_fwd<true, false>(nch, x, residual, gamma, beta, rows, D, eps, sum_out, y, mean, rstd, st);
+  } else {
+    if (param_dtype == VQAF_BF16) launch_ln_fwd<false, true>(nch, x, residual, gamma, beta, rows, D, eps, sum_out, y, mean, rstd, st);
+    else launch_ln_fwd<false, false>(nch, x, residual, gamma, beta, rows, D, eps, sum_out, y, mean, rstd, st);
+  }
   VQAF_LAUNCH_CHECK();
 }
 
-extern "C" int vqaf_layernorm_bwd(const void* dy, const void* s, const float* gamma, const float* mean,
-                                  const float* rstd, const void* dsum_in, long rows, int D, int dtype, void* dx,
-                                  float* dgamma, float* dbeta, vqaf_stream_t stream) {
+extern "C" size_t vqaf_layernorm_bwd_workspace_bytes(long rows, int D) {
+  if (rows <= 0 || D <= 0) return 0;
+  return (size_t)((rows + LN_ROWS - 1) / LN_ROWS) * 2 * (size_t)D * sizeof(float);
+}
+
+extern "C" int vqaf_layernorm_bwd(const void* dy, const void* s, const void* gamma, int param_dtype,
+                                  const float* mean, const float* rstd, const void* dsum_in, long rows, int D,
+                                  int dtype, void* dx, void* dgamma, void* dbeta, void* workspace,
+                                  size_t workspace_bytes, vqaf_stream_t stream) {
   VQAF_ENTRY();
-  VQAF_REQUIRE(dy && s && gamma && mean && rstd && dx && dgamma && dbeta, VQAF_E_NULL);
-  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(dy && s && gamma && mean && rstd && dx && dgamma && dbeta && workspace, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(param_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(rows > 0 && D > 0 && D <= 2048 && D % 8 == 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(workspace_bytes >= vqaf_layernorm_bwd_workspace_bytes(rows, D), VQAF_E_SHAPE);
   VQAF_REQUIRE(vqaf_aligned16(dy) && vqaf_aligned16(s) && vqaf_aligned16(dx) && vqaf_aligned16(gamma) &&
-                   (!dsum_in || vqaf_aligned16(dsum_in)), VQAF_E_ALIGN);
+                   vqaf_aligned16(workspace) && (!dsum_in || vqaf_aligned16(dsum_in)), VQAF_E_ALIGN);
   const int nch = ln_chunks(D);
-  if (dtype == VQAF_BF16) launch_ln_bwd<true>(nch, dy, s, gamma, mean, rstd, dsum_in, rows, D, dx, dgamma, dbeta, (hipStream_t)stream);
-  else launch_ln_bwd<false>(nch, dy, s, gamma, mean, rstd, dsum_in, rows, D, dx, dgamma, dbeta, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  if (dtype == VQAF_BF16) {
+    if (param_dtype == VQAF_BF16) launch_ln_bwd<true, true>(nch, dy, s, gamma, mean, rstd, dsum_in, rows, D, dx, part, st);
+    else launch_ln_bwd<true, false>(nch, dy, s, gamma, mean, rstd, dsum_in, rows, D, dx, part, st);
+  } else {
+    if (param_dtype == VQAF_BF16) launch_ln_bwd<false, true>(nch, dy, s, gamma, mean, rstd, dsum_in, rows, D, dx, part, st);
+    else launch_ln_bwd<false, false>(nch, dy, s, gamma, mean, rstd, dsum_in, rows, D, dx, part, st);
+  }
+  const int nblk = (int)((rows + LN_ROWS - 1) / LN_ROWS);
+  const dim3 grid((2 * D + 15) / 16);
+  if (param_dtype == VQAF_BF16) hipLaunchKernelGGL(layernorm_param_grad_kernel<true>, grid, dim3(256), 0, st, part, nblk, D, dgamma, dbeta);
+  else hipLaunchKernelGGL(layernorm_param_grad_kernel<false>, grid, dim3(256), 0, st, part, nblk, D, dgamma, dbeta);
   VQAF_LAUNCH_CHECK();
 }
 

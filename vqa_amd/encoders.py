@@ -86,17 +86,16 @@ class _AddLayerNorm(torch.autograd.Function):
         xc = x.contiguous()
         rc = None if residual is None else residual.to(x.dtype).contiguous()
         rows = xc.numel() // D
-        g = weight.detach().to(torch.float32).contiguous()
-        b = bias.detach().to(torch.float32).contiguous()
+        g = weight.detach().contiguous()
+        b = bias.detach().to(g.dtype).contiguous()
         y = torch.empty_like(xc)
         s = torch.empty_like(xc) if rc is not None else xc
         stats = torch.empty(2, rows, dtype=torch.float32, device=x.device)
-        check(load().vqaf_layernorm_fwd(ptr(xc), ptr(rc), ptr(g), ptr(b), rows, D, float(eps), dtype_code(xc),
-                                        ptr(s) if rc is not None else None, ptr(y), ptr(stats[0]), ptr(stats[1]),
-                                        stream_ptr(x.device)), "vqaf_layernorm_fwd")
+        check(load().vqaf_layernorm_fwd(ptr(xc), ptr(rc), ptr(g), ptr(b), dtype_code(g), rows, D, float(eps),
+                                        dtype_code(xc), ptr(s) if rc is not None else None, ptr(y), ptr(stats[0]),
+                                        ptr(stats[1]), stream_ptr(x.device)), "vqaf_layernorm_fwd")
         ctx.save_for_backward(s, g, stats)
         ctx.has_res = rc is not None
-        ctx.wdtype = weight.dtype
         ctx.set_materialize_grads(False)
         return (y, s) if rc is not None else y
 
@@ -110,11 +109,13 @@ class _AddLayerNorm(torch.autograd.Function):
         gy = gy.to(s.dtype).contiguous()
         gsc = None if gs is None else gs.to(s.dtype).contiguous()
         dx = torch.empty_like(s)
-        dgb = torch.zeros(2, D, dtype=torch.float32, device=s.device)
-        check(load().vqaf_layernorm_bwd(ptr(gy), ptr(s), ptr(g), ptr(stats[0]), ptr(stats[1]), ptr(gsc), rows, D,
-                                        dtype_code(s), ptr(dx), ptr(dgb[0]), ptr(dgb[1]), stream_ptr(s.device)),
-              "vqaf_layernorm_bwd")
-        return dx, (dx if ctx.has_res else None), dgb[0].to(ctx.wdtype), dgb[1].to(ctx.wdtype), None
+        dgb = torch.empty(2, D, dtype=g.dtype, device=s.device)
+        nbytes = load().vqaf_layernorm_bwd_workspace_bytes(rows, D)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=s.device)
+        check(load().vqaf_layernorm_bwd(ptr(gy), ptr(s), ptr(g), dtype_code(g), ptr(stats[0]), ptr(stats[1]), ptr(gsc),
+                                        rows, D, dtype_code(s), ptr(dx), ptr(dgb[0]), ptr(dgb[1]), ptr(ws), nbytes,
+                                        stream_ptr(s.device)), "vqaf_layernorm_bwd")
+        return dx, (dx if ctx.has_res else None), dgb[0], dgb[1], None
 
 
 def add_layer_norm(x, residual, weight, bias, eps):
@@ -147,12 +148,59 @@ def gelu(x: torch.Tensor) -> torch.Tensor:
     return _Gelu.apply(x)
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b for bf16 activations.  Forward and input gradient are plain library GEMMs; the weight
+    gradient dW = dY^T X contracts over the token index, which is the SLOW index of both operands: that is
+    the layout of the clipped-sum GEMM of the DP step, so it runs on the same kernel (vqaf_gemm_bf16, both
+    operands k-major), which also delivers the bias gradient (column sums of dY) from an extra MFMA instead
+    of a second pass over dY."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        ctx.bdtype = None if b is None else b.dtype
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x, w = ctx.saved_tensors
+        out_f, in_f = w.shape
+        gy2 = gy.reshape(-1, out_f)
+        if not gy2.is_contiguous():
+            gy2 = gy2.contiguous()
+        x2 = x.reshape(-1, in_f)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T = x2.shape[0]
+        gx = torch.mm(gy2, w).view(x.shape) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            if ops.gemm_bf16_supported(out_f, True, in_f, True, out_f, in_f, T):
+                gw32 = torch.empty(out_f, in_f, dtype=torch.float32, device=x.device)
+                cs = torch.empty(out_f, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+                ops.gemm_bf16(gy2, True, x2, True, out_f, in_f, T, gw32, colsum=cs)
+                gw = gw32.to(w.dtype)
+                gb = None if cs is None else cs.to(ctx.bdtype)
+            else:  # row pitches the kernel does not cover (not multiples of 8): library GEMM
+                gw = torch.mm(gy2.t(), x2)
+                gb = gy2.sum(0).to(ctx.bdtype) if ctx.has_bias else None
+        return gx, gw, gb
+
+
+def _affine(x, w, b):
+    if x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16:
+        return _LinearFn.apply(x, w, b)
+    return F.linear(x, w, b)
+
+
 def _linear(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
     w, b = lin.weight, lin.bias
     if w.dtype != x.dtype:
         w = w.to(x.dtype)
         b = None if b is None else b.to(x.dtype)
-    return F.linear(x, w, b)
+    return _affine(x, w, b)
 
 
 def _packed_qkv(x, q: nn.Linear, k: nn.Linear, v: nn.Linear) -> torch.Tensor:
@@ -161,7 +209,7 @@ def _packed_qkv(x, q: nn.Linear, k: nn.Linear, v: nn.Linear) -> torch.Tensor:
     b = torch.cat([q.bias, k.bias, v.bias], 0)
     if w.dtype != x.dtype:
         w, b = w.to(x.dtype), b.to(x.dtype)
-    return F.linear(x, w, b)
+    return _affine(x, w, b)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -240,7 +288,7 @@ class _ViTPatchEmbeddings(nn.Module):
         b = self.projection.bias
         if w.dtype != rows.dtype:
             w, b = w.to(rows.dtype), b.to(rows.dtype)
-        return F.linear(rows, w, b)
+        return _affine(rows, w, b)
 
 
 class _ViTEmbeddings(nn.Module):
