@@ -514,19 +514,23 @@ int vqaf_scale_cast(const float* in, const float* scale, size_t n, int out_dtype
  * blocks of one packed projection output); key_bias (B,N) f32 additive or NULL (the extended
  * attention mask of BertModel: 0 for tokens, a large negative number for padding); out (B, N, ld_o);
  * lse (B,H,N) f32 receives the base-2 logarithm of the softmax denominator in the scaled domain
- * (what vqaf_attn_bwd needs).  Row pitches are in elements and multiples of 8. */
+ * (what vqaf_attn_bwd needs).  Row pitches are in elements and multiples of 8.
+ * dropout_p > 0 drops attention probabilities after the softmax (attention_probs_dropout_prob of the
+ * BERT config, active in train mode): probability (b,h,n,m) is kept, and scaled by 1/(1-p), iff word
+ * m%4 of the Philox4x32-10 call (seed, counter, ((b*H+h)*N+n)*ceil(N/4) + m/4) is >= p*2^32, with
+ * {seed, counter} = dropout_state[0..1] in device memory (read at run time; not advanced). */
 int vqaf_attn_fwd(const void* q, const void* k, const void* v, long ld_qkv, const float* key_bias,
-                  int B, int H, int N, int dh, float scale, void* out, long ld_o, float* lse,
-                  vqaf_stream_t stream);
+                  int B, int H, int N, int dh, float scale, float dropout_p,
+                  const uint64_t* dropout_state, void* out, long ld_o, float* lse, vqaf_stream_t stream);
 
 /* Backward of vqaf_attn_fwd: dq, dk, dv (B, N, ld_d) bf16 from dout (B, N, ld_o) and the forward's
  * lse; the forward output itself is not needed (the row term of the softmax backward is recomputed
  * from the probabilities, which keeps sum_m ds[n,m] = 0 to f32 rounding).  dvec (B,H,N) f32 is
- * workspace. */
+ * workspace.  dropout_p / dropout_state: the values the forward call saw (a copy of its state). */
 int vqaf_attn_bwd(const void* q, const void* k, const void* v, long ld_qkv, const float* key_bias,
                   const void* dout, long ld_o, const float* lse, int B, int H, int N,
-                  int dh, float scale, void* dq, void* dk, void* dv, long ld_d, float* dvec,
-                  vqaf_stream_t stream);
+                  int dh, float scale, float dropout_p, const uint64_t* dropout_state, void* dq, void* dk,
+                  void* dv, long ld_d, float* dvec, vqaf_stream_t stream);
 
 /* LayerNorm over the last dimension with the residual add in front of it (nn.LayerNorm of the
  * BertSelfOutput / BertOutput / ViTLayer blocks): s = x (+ residual), y = LN(s) * gamma + beta.

@@ -68,6 +68,68 @@ def test_attention_forward_and_backward(B, H, N, masked):
         assert float(gk[dead].abs().max()) == 0.0 and float(gv[dead].abs().max()) == 0.0
 
 
+def _host_keep_scale(seed, counter, B, H, N, p):
+    """mask / (1 - p) of every (b,h,n,m) from the host restatement of the generator."""
+    import numpy as np
+    import philox_np
+    groups = (N + 3) // 4
+    calls = np.arange(B * H * N * groups, dtype=np.uint64)
+    words = philox_np.philox4x32_10(seed, calls, counter).reshape(B, H, N, groups * 4)[..., :N]
+    thr = min(int(p * 4294967296.0), 4294967295)
+    return torch.from_numpy((words >= np.uint32(thr)).astype(np.float64) / (1.0 - p))
+
+
+@pytest.mark.parametrize("B,H,N,p", [(2, 2, 30, 0.1), (1, 3, 64, 0.25), (2, 2, 197, 0.1)])
+def test_attention_dropout_mask_values_and_gradients(B, H, N, p):
+    """The mask is the documented function of (seed, counter, b, h, n, m): the forward applies it after the
+    softmax, the backward regenerates it; the state's counter moves by one per call."""
+    from vqa_amd import ops
+    rng = ops.PhiloxState(DEV, seed=1234 + N)
+    rng.advance(3)
+    qkv = _qkv(B, N, H, seed=N, spread=1.2)
+    x = qkv.to(DEV).requires_grad_()
+    out = encoders.self_attention(x, None, H, p, rng)
+    assert rng.state.cpu().tolist()[1] == 4
+    cot = torch.randn(B, N, H * 64, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16)
+    out.backward(cot.to(DEV))
+    keep = _host_keep_scale(rng.seed, 3, B, H, N, p)
+    assert abs(float((keep > 0).double().mean()) - (1 - p)) < 0.02
+    ref_in = qkv.double().requires_grad_()
+    q, k, v = _split(ref_in, H)
+    probs = torch.softmax((q @ k.transpose(-1, -2)) * 0.125, dim=-1) * keep
+    ref = (probs @ v).transpose(1, 2).reshape(B, N, H * 64)
+    ref.backward(cot.double())
+    assert _rel(out, ref) < 6e-3, _rel(out, ref)
+    assert _rel(x.grad, ref_in.grad) < 1.2e-2, _rel(x.grad, ref_in.grad)
+    # a second call draws a different mask, p = 0 none at all
+    out2 = encoders.self_attention(x.detach(), None, H, p, rng)
+    assert _rel(out2, ref) > 0.05
+    out0 = encoders.self_attention(x.detach(), None, H, 0.0, None)
+    clean = (torch.softmax((q @ k.transpose(-1, -2)) * 0.125, dim=-1) @ v).transpose(1, 2).reshape(B, N, H * 64)
+    assert _rel(out0, clean) < 6e-3
+
+
+def test_bert_train_mode_applies_both_dropouts_and_eval_does_not():
+    torch.manual_seed(4)
+    cfg = encoders.BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                              vocab_size=101, max_position_embeddings=40)
+    m = encoders.BertModel(cfg).to(DEV)
+    ids = torch.randint(1, 101, (3, 12), device=DEV)
+    mask = torch.ones(3, 12, dtype=torch.long, device=DEV)
+    m.eval()
+    with torch.no_grad():
+        e1, _ = m(ids, mask)
+        e2, _ = m(ids, mask)
+    assert torch.equal(e1, e2)
+    m.train()
+    t1, _ = m(ids, mask)
+    t2, pooled = m(ids, mask)
+    assert not torch.equal(t1, t2)
+    assert m._attn_rng.state.cpu().tolist()[1] == 4  # two layers, two calls
+    (t2.float().sum() + pooled.float().sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
 def test_attention_fully_masked_row_is_uniform_and_finite():
     B, H, N = 2, 2, 9
     qkv = _qkv(B, N, H, seed=1).to(DEV)
@@ -180,7 +242,8 @@ def test_vit_stack_matches_oracle_forward_and_gradients():
 def test_bert_stack_matches_oracle_forward_and_gradients_with_padding():
     torch.manual_seed(1)
     cfg = encoders.BertConfig(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
-                              vocab_size=101, max_position_embeddings=40, hidden_dropout_prob=0.0)
+                              vocab_size=101, max_position_embeddings=40, hidden_dropout_prob=0.0,
+                              attention_probs_dropout_prob=0.0)
     m = encoders.BertModel(cfg)
     with torch.no_grad():
         for p in m.parameters():

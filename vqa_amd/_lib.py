@@ -127,9 +127,10 @@ SIGNATURES = {
                                    _P]),
     "vqaf_ce_conf": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P]),
     "vqaf_scale_cast": (c_int, [_P, _P, c_size_t, c_int, _P, _P]),
-    "vqaf_attn_fwd": (c_int, [_P, _P, _P, c_long, _P, c_int, c_int, c_int, c_int, c_float, _P, c_long, _P, _P]),
-    "vqaf_attn_bwd": (c_int, [_P, _P, _P, c_long, _P, _P, c_long, _P, c_int, c_int, c_int, c_int, c_float,
-                              _P, _P, _P, c_long, _P, _P]),
+    "vqaf_attn_fwd": (c_int, [_P, _P, _P, c_long, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, c_long,
+                              _P, _P]),
+    "vqaf_attn_bwd": (c_int, [_P, _P, _P, c_long, _P, _P, c_long, _P, c_int, c_int, c_int, c_int, c_float, c_float,
+                              _P, _P, _P, _P, c_long, _P, _P]),
     "vqaf_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_int, c_long, c_int, c_float, c_int, _P, _P, _P, _P, _P]),
     "vqaf_layernorm_bwd_workspace_bytes": (c_size_t, [c_long, c_int]),
     "vqaf_layernorm_bwd": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_long, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),

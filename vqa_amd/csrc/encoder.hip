@@ -42,7 +42,22 @@ struct AttnArgs {
   long ld_qkv, ld_o, ld_d;
   int N, H;
   float scale;               // 1/sqrt(dh)
+  // dropout on the attention probabilities: element (b,h,n,m) is kept iff word (m%4) of the Philox call
+  // (seed, counter, ((b*H+h)*N + n) * ceil(N/4) + m/4) is >= drop_thr; kept values are scaled by drop_inv
+  const uint64_t* drop_state;  // {seed, counter} in device memory, or null
+  unsigned int drop_thr;
+  float drop_inv;
 };
+
+// keep-scale factors of four consecutive keys 4*group .. 4*group+3 of one query row
+__device__ __forceinline__ void drop_scale4(unsigned long long seed, unsigned long long ctr, unsigned long long row,
+                                            int groups, int group, unsigned int thr, float inv, float (&mk)[4]) {
+  const Philox4 r = philox4x32_10(seed, row * (unsigned long long)groups + (unsigned long long)group, ctr);
+  mk[0] = r.x >= thr ? inv : 0.f;
+  mk[1] = r.y >= thr ? inv : 0.f;
+  mk[2] = r.z >= thr ? inv : 0.f;
+  mk[3] = r.w >= thr ? inv : 0.f;
+}
 
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
           if (kb * AT_BLK + sb * 32 >= N) break;
-          body(sb);
+          body(sb, kb * AT_BLK + sb * 32);
         }
       }
       __syncthreads();
@@ -209,6 +224,21 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
     }
     return s;
   };
+  const bool drop = a.drop_state != nullptr;  // uniform
+  unsigned long long dseed = 0, dctr = 0;
+  if (drop) { dseed = a.drop_state[0]; dctr = a.drop_state[1]; }
+  const unsigned long long drow = ((unsigned long long)b * a.H + h) * N + (unsigned long long)(q0 + j);
+  const int dgroups = (N + 3) >> 2;
+  // w[r] *= keep-scale of (query of this lane, key of register r)
+  auto apply_drop = [&](int key0, f32x16& w) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float mk[4];
+      drop_scale4(dseed, dctr, drow, dgroups, (key0 >> 2) + 2 * g + hh, a.drop_thr, a.drop_inv, mk);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[4 * g + e] *= mk[e];
+    }
+  };
   auto second_product = [&](int sb, const f32x16& w) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -219,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
   };
 
   if constexpr (MODE == 0) {
-    stream_keys([&](int sb) {
+    stream_keys([&](int sb, int key0) {
       f32x16 s = scores(sb);
       float mx = s[0];
 #pragma unroll
@@ -239,6 +269,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+      if (drop) apply_drop(key0, s);  // after the row sum: the softmax is normalised over every key
       second_product(sb, s);
     });
   } else {
@@ -257,17 +288,19 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
     // pass 2.  (rowsum(dO * O) equals it in exact arithmetic, but O is stored rounded to bf16 and the
     // difference does not cancel in sum_m ds[n,m] k_m: it shows up as an error of dq proportional to |dO||O|.)
     float dacc = 0.f;
-    stream_keys([&](int sb) {
+    stream_keys([&](int sb, int key0) {
       const f32x16 s = scores(sb);
-      const f32x16 dp = dprobs(sb);
+      f32x16 dp = dprobs(sb);
+      if (drop) apply_drop(key0, dp);  // d(prob) = mask/(1-p) * d(dropped prob)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dacc += __builtin_amdgcn_exp2f(s[r] - l2) * dp[r];
     });
     dsum = dacc + xchg32(dacc);
     if (active && hh == 0 && q0 + j < N) a.dvec[((size_t)b * a.H + h) * N + q0 + j] = dsum;
-    stream_keys([&](int sb) {
+    stream_keys([&](int sb, int key0) {
       f32x16 s = scores(sb);
-      const f32x16 dp = dprobs(sb);
+      f32x16 dp = dprobs(sb);
+      if (drop) apply_drop(key0, dp);
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - l2) * (dp[r] - dsum);
       second_product(sb, s);
@@ -318,6 +351,12 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(const AttnArgs a) {
   }
   float kbias = 0.f;
   if (a.key_bias != nullptr) kbias = fmaxf(a.key_bias[(size_t)b * N + krow], AT_MIN_BIAS) * AT_LOG2E;
+  const bool drop = a.drop_state != nullptr;  // uniform
+  unsigned long long dseed = 0, dctr = 0;
+  if (drop) { dseed = a.drop_state[0]; dctr = a.drop_state[1]; }
+  const unsigned long long rowbase = ((unsigned long long)b * a.H + h) * N;
+  const int dgroups = (N + 3) >> 2;
+  const int krow_true = k0 + j;
 
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -372,8 +411,15 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(const AttnArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float p = __builtin_amdgcn_exp2f(s[4 * g + e] * c2 + kbias - lv[e]);
-            s[4 * g + e] = p;
-            dp[4 * g + e] = p * (dp[4 * g + e] - dvv[e]);
+            float mk = 1.f;
+            if (drop) {  // the word of this lane's key in the call of the register's query row
+              const unsigned long long row = rowbase + (unsigned long long)(qb * AT_BLK + sb * 32 + 8 * g + 4 * hh + e);
+              const Philox4 r = philox4x32_10(dseed, row * (unsigned long long)dgroups + (unsigned long long)(krow_true >> 2), dctr);
+              const unsigned int w4[4] = {r.x, r.y, r.z, r.w};
+              mk = w4[krow_true & 3] >= a.drop_thr ? a.drop_inv : 0.f;
+            }
+            s[4 * g + e] = p * mk;                                  // dropped probability: dV = P~^T dO
+            dp[4 * g + e] = p * (mk * dp[4 * g + e] - dvv[e]);
           }
         }
 #pragma unroll
@@ -616,8 +662,23 @@ int attn_check(const void* q, const void* k, const void* v, long ld_qkv, long ld
 
 }  // namespace
 
+namespace {
+int attn_dropout(AttnArgs& a, float p, const uint64_t* state) {
+  VQAF_REQUIRE(p >= 0.f && p < 1.f, VQAF_E_SHAPE);
+  a.drop_state = nullptr;
+  if (p > 0.f) {
+    VQAF_REQUIRE(state != nullptr, VQAF_E_NULL);
+    a.drop_state = state;
+    a.drop_thr = (unsigned int)fmin((double)p * 4294967296.0, 4294967295.0);
+    a.drop_inv = 1.0f / (1.0f - p);
+  }
+  return VQAF_OK;
+}
+}  // namespace
+
 extern "C" int vqaf_attn_fwd(const void* q, const void* k, const void* v, long ld_qkv, const float* key_bias,
-                             int B, int H, int N, int dh, float scale, void* out, long ld_o, float* lse,
+                             int B, int H, int N, int dh, float scale, float dropout_p,
+                             const uint64_t* dropout_state, void* out, long ld_o, float* lse,
                              vqaf_stream_t stream) {
   VQAF_ENTRY();
   const int rc = attn_check(q, k, v, ld_qkv, ld_o, B, H, N, dh);
@@ -628,6 +689,8 @@ extern "C" int vqaf_attn_fwd(const void* q, const void* k, const void* v, long l
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
   a.out = (bf16_t*)out; a.key_bias = key_bias; a.lse = lse;
   a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.N = N; a.H = H; a.scale = scale;
+  const int rd = attn_dropout(a, dropout_p, dropout_state);
+  if (rd != VQAF_OK) return rd;
   const dim3 grid((N + AT_OWN - 1) / AT_OWN, H, B);
   hipLaunchKernelGGL(attn_q_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
   VQAF_LAUNCH_CHECK();
@@ -635,8 +698,8 @@ extern "C" int vqaf_attn_fwd(const void* q, const void* k, const void* v, long l
 
 extern "C" int vqaf_attn_bwd(const void* q, const void* k, const void* v, long ld_qkv, const float* key_bias,
                              const void* dout, long ld_o, const float* lse, int B, int H, int N,
-                             int dh, float scale, void* dq, void* dk, void* dv, long ld_d, float* dvec,
-                             vqaf_stream_t stream) {
+                             int dh, float scale, float dropout_p, const uint64_t* dropout_state, void* dq,
+                             void* dk, void* dv, long ld_d, float* dvec, vqaf_stream_t stream) {
   VQAF_ENTRY();
   const int rc = attn_check(q, k, v, ld_qkv, ld_o, B, H, N, dh);
   if (rc != VQAF_OK) return rc;
@@ -651,6 +714,8 @@ extern "C" int vqaf_attn_bwd(const void* q, const void* k, const void* v, long l
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
   a.key_bias = key_bias; a.lse = const_cast<float*>(lse); a.dvec = dvec;
   a.ld_qkv = ld_qkv; a.ld_o = ld_o; a.ld_d = ld_d; a.N = N; a.H = H; a.scale = scale;
+  const int rd = attn_dropout(a, dropout_p, dropout_state);
+  if (rd != VQAF_OK) return rd;
   const dim3 grid((N + AT_OWN - 1) / AT_OWN, H, B);
   hipLaunchKernelGGL(attn_q_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);   // dQ, and the softmax row terms for the next launch
   hipLaunchKernelGGL(attn_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);

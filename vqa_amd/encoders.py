@@ -33,10 +33,10 @@ from ._lib import check, dtype_code, load, ptr, stream_ptr
 # autograd wrappers of the kernels
 # --------------------------------------------------------------------------------------------------
 class _SelfAttention(torch.autograd.Function):
-    """ctx (B,N,E) <- packed qkv (B,N,3E) bf16: softmax(q k^T / sqrt(dh) + key_bias) v per head."""
+    """ctx (B,N,E) <- packed qkv (B,N,3E) bf16: dropout(softmax(q k^T / sqrt(dh) + key_bias)) v per head."""
 
     @staticmethod
-    def forward(ctx, qkv, key_bias, heads):
+    def forward(ctx, qkv, key_bias, heads, dropout_p, rng):
         B, N, E3 = qkv.shape
         E = E3 // 3
         if qkv.dtype != torch.bfloat16:
@@ -47,17 +47,25 @@ class _SelfAttention(torch.autograd.Function):
         kb = None if key_bias is None else key_bias.to(torch.float32).contiguous()
         out = torch.empty(B, N, E, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
+        drop = None
+        if dropout_p > 0.0:
+            drop = rng.state.clone()  # the backward regenerates the mask from the same {seed, counter}
         base = ptr(qkv)
         check(load().vqaf_attn_fwd(base, base + 2 * E, base + 4 * E, E3, ptr(kb), B, heads, N, 64, 1.0 / 8.0,
-                                   ptr(out), E, ptr(lse), stream_ptr(qkv.device)), "vqaf_attn_fwd")
-        ctx.save_for_backward(qkv, lse, kb if kb is not None else lse.new_empty(0))
+                                   float(dropout_p), ptr(drop), ptr(out), E, ptr(lse), stream_ptr(qkv.device)),
+              "vqaf_attn_fwd")
+        if drop is not None:
+            rng.advance(1)
+        empty = lse.new_empty(0)
+        ctx.save_for_backward(qkv, lse, kb if kb is not None else empty, drop if drop is not None else empty)
         ctx.heads = heads
         ctx.has_bias = kb is not None
+        ctx.dropout_p = float(dropout_p)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        qkv, lse, kb = ctx.saved_tensors
+        qkv, lse, kb, drop = ctx.saved_tensors
         B, N, E3 = qkv.shape
         E = E3 // 3
         g = grad_out.contiguous()
@@ -67,14 +75,19 @@ class _SelfAttention(torch.autograd.Function):
         dvec = torch.empty_like(lse)
         base, dbase = ptr(qkv), ptr(dqkv)
         check(load().vqaf_attn_bwd(base, base + 2 * E, base + 4 * E, E3, ptr(kb) if ctx.has_bias else None,
-                                   ptr(g), E, ptr(lse), B, ctx.heads, N, 64, 1.0 / 8.0,
+                                   ptr(g), E, ptr(lse), B, ctx.heads, N, 64, 1.0 / 8.0, ctx.dropout_p,
+                                   ptr(drop) if ctx.dropout_p > 0.0 else None,
                                    dbase, dbase + 2 * E, dbase + 4 * E, E3, ptr(dvec), stream_ptr(qkv.device)),
               "vqaf_attn_bwd")
-        return dqkv, None, None
+        return dqkv, None, None, None, None
 
 
-def self_attention(qkv: torch.Tensor, key_bias: torch.Tensor | None, heads: int) -> torch.Tensor:
-    return _SelfAttention.apply(qkv, key_bias, heads)
+def self_attention(qkv: torch.Tensor, key_bias: torch.Tensor | None, heads: int, dropout_p: float = 0.0,
+                   rng=None) -> torch.Tensor:
+    """`rng`: an ops.PhiloxState on qkv's device (required when dropout_p > 0); its counter is advanced by one."""
+    if dropout_p > 0.0 and rng is None:
+        raise ValueError("attention dropout needs a generator state")
+    return _SelfAttention.apply(qkv, key_bias, heads, float(dropout_p), rng)
 
 
 class _AddLayerNorm(torch.autograd.Function):
@@ -227,6 +240,7 @@ class ViTConfig:
     num_channels: int = 3
     layer_norm_eps: float = 1e-12
     hidden_dropout_prob: float = 0.0
+    attention_probs_dropout_prob: float = 0.0
     initializer_range: float = 0.02
 
 
@@ -242,6 +256,7 @@ class BertConfig:
     type_vocab_size: int = 2
     layer_norm_eps: float = 1e-12
     hidden_dropout_prob: float = 0.1
+    attention_probs_dropout_prob: float = 0.1
     pad_token_id: int = 0
     initializer_range: float = 0.02
 
@@ -263,6 +278,18 @@ def _init_weights(module: nn.Module, std: float) -> None:
         elif isinstance(m, nn.LayerNorm):
             nn.init.ones_(m.weight)
             nn.init.zeros_(m.bias)
+
+
+def _dropout_rng(module: nn.Module, device: torch.device):
+    """The module's generator state for attention dropout (made on first use, seeded from torch's seed,
+    rank-dependent so that data-parallel replicas draw different masks)."""
+    from . import ops
+    st = getattr(module, "_attn_rng", None)
+    if st is None or st.state.device != device:
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        st = ops.PhiloxState(device, stream_salt=41 + 1009 * rank)
+        module._attn_rng = st
+    return st
 
 
 # --------------------------------------------------------------------------------------------------
@@ -341,12 +368,14 @@ class _ViTLayer(nn.Module):
         self.layernorm_before = nn.LayerNorm(E, eps=cfg.layer_norm_eps)
         self.layernorm_after = nn.LayerNorm(E, eps=cfg.layer_norm_eps)
         self.heads, self.eps, self.p = cfg.num_attention_heads, cfg.layer_norm_eps, cfg.hidden_dropout_prob
+        self.p_attn = cfg.attention_probs_dropout_prob
 
-    def forward(self, y, s):
+    def forward(self, y, s, rng=None):
         """y = layernorm_before(s) of this layer; returns (layernorm of the NEXT consumer's input, stream)
         as a pair so that every residual add runs inside the LayerNorm kernel that follows it."""
         a = self.attention.attention
-        ctx = self_attention(_packed_qkv(y, a.query, a.key, a.value), None, self.heads)
+        ctx = self_attention(_packed_qkv(y, a.query, a.key, a.value), None, self.heads,
+                             self.p_attn if self.training else 0.0, rng)
         att = F.dropout(_linear(ctx, self.attention.output.dense), self.p, self.training)
         y2, s2 = add_layer_norm(att, s, self.layernorm_after.weight, self.layernorm_after.bias, self.eps)
         h = gelu(_linear(y2, self.intermediate.dense))
@@ -388,10 +417,11 @@ class ViTModel(nn.Module):
         # block i:  s <- s + attn(LN1_i(s));  s <- s + mlp(LN2_i(s)).  Each add is done by the LayerNorm kernel
         # that consumes the sum, so the loop carries (pending branch output, stream before the add).
         pending, s = None, x
+        rng = _dropout_rng(self, x.device) if self.training and self.config.attention_probs_dropout_prob > 0 else None
         for lyr in self.encoder.layer:
             y, s = add_layer_norm(s if pending is None else pending, None if pending is None else s,
                                   lyr.layernorm_before.weight, lyr.layernorm_before.bias, lyr.eps)
-            pending, s = lyr(y, s)
+            pending, s = lyr(y, s, rng)
         h, _ = add_layer_norm(pending, s, self.layernorm.weight, self.layernorm.bias, self.config.layer_norm_eps)
         return h, self.pooler(h)
 
@@ -445,10 +475,12 @@ class _BertLayer(nn.Module):
         self.intermediate = _Dense(E, cfg.intermediate_size)
         self.output = _BertSelfOutput(cfg.intermediate_size, E, cfg.layer_norm_eps)
         self.heads, self.eps, self.p = cfg.num_attention_heads, cfg.layer_norm_eps, cfg.hidden_dropout_prob
+        self.p_attn = cfg.attention_probs_dropout_prob
 
-    def forward(self, x, key_bias):
+    def forward(self, x, key_bias, rng=None):
         a = self.attention.self
-        ctx = self_attention(_packed_qkv(x, a.query, a.key, a.value), key_bias, self.heads)
+        ctx = self_attention(_packed_qkv(x, a.query, a.key, a.value), key_bias, self.heads,
+                             self.p_attn if self.training else 0.0, rng)
         att = F.dropout(_linear(ctx, self.attention.output.dense), self.p, self.training)
         ln = self.attention.output.LayerNorm
         x1, _ = add_layer_norm(att, x, ln.weight, ln.bias, self.eps)
@@ -478,8 +510,9 @@ class BertModel(nn.Module):
         if attention_mask is not None:
             # the extended mask of BertModel: 0 where attended, a large negative number on padding
             key_bias = (1.0 - attention_mask.to(torch.float32)) * -1.0e30
+        rng = _dropout_rng(self, x.device) if self.training and self.config.attention_probs_dropout_prob > 0 else None
         for lyr in self.encoder.layer:
-            x = lyr(x, key_bias)
+            x = lyr(x, key_bias, rng)
         return x, self.pooler(x)
 
 
