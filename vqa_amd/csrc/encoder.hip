@@ -16,6 +16,8 @@
 // a 16-row step is a fixed permutation that the A operand is read with as well).  A operands
 // that need the contraction index down a column of a row-major tile (V^T, K^T, Q^T, dO^T) come
 // from LDS through the transposing read ds_read_b64_tr_b16.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -122,8 +124,8 @@ __device__ __forceinline__ void store_owned(bf16_t* row_ptr, const f32x16 (&acc)
 // ----------------------------------------------------------------------------------------------
 // Forward (MODE 0) and the dQ half of the backward (MODE 1): a wave owns 32 queries, K and V stream
 // through LDS in blocks of 64 keys.
-template <int MODE>
-__global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
+template <int MODE, bool DROP>
+__global__ __launch_bounds__(256, 3) void attn_q_kernel(const AttnArgs a) {
   __shared__ __align__(16) bf16_t Kr[AT_BLK * AT_PR];                       // K by rows (S^T = K Q^T)
   __shared__ __align__(16) bf16_t Xt[AT_BLK * AT_PT];                       // forward: V, backward: K, transposed reads
   __shared__ __align__(16) bf16_t Vr[MODE == 1 ? AT_BLK * AT_PR : 8];       // backward: V by rows (dP^T = V dO^T)
@@ -192,18 +194,20 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
     __syncthreads();
     for (int kb = 0; kb < nblk; ++kb) {
       if (kb + 1 < nblk) issue(kb + 1);
-      if (active) {
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-          if (kb * AT_BLK + sb * 32 >= N) break;
-          body(sb, kb * AT_BLK + sb * 32);
-        }
-      }
+      if (active) body(kb);
       __syncthreads();
       if (kb + 1 < nblk) {
         commit();
         __syncthreads();
       }
+    }
+  };
+  // body(sub-block, first key) on every 32-key sub-block of block kb that holds a key
+  auto each_sub = [&](int kb, auto&& body) {
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      if (kb * AT_BLK + sb * 32 >= N) break;
+      body(sb, kb * AT_BLK + sb * 32);
     }
   };
   // scaled, biased scores of a sub-block in the base-2 domain (rows = keys, lane column = the query)
@@ -224,9 +228,8 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
     }
     return s;
   };
-  const bool drop = a.drop_state != nullptr;  // uniform
   unsigned long long dseed = 0, dctr = 0;
-  if (drop) { dseed = a.drop_state[0]; dctr = a.drop_state[1]; }
+  if constexpr (DROP) { dseed = a.drop_state[0]; dctr = a.drop_state[1]; }
   const unsigned long long drow = ((unsigned long long)b * a.H + h) * N + (unsigned long long)(q0 + j);
   const int dgroups = (N + 3) >> 2;
   // w[r] *= keep-scale of (query of this lane, key of register r)
@@ -249,28 +252,45 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
   };
 
   if constexpr (MODE == 0) {
-    stream_keys([&](int sb, int key0) {
-      f32x16 s = scores(sb);
-      float mx = s[0];
+    // The online-softmax step covers NS sub-blocks at once: their score products are independent MFMA
+    // chains, and the running maximum, the rescaling of the accumulators and the lane exchange are paid
+    // once per 64 keys.
+    auto step = [&](auto ns_tag, int kb) {
+      constexpr int NS = decltype(ns_tag)::value;
+      f32x16 s[NS];
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      for (int i = 0; i < NS; ++i) s[i] = scores(i);
+      float mx = s[0][0];
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[i][r]);
       mx = fmaxf(mx, xchg32(mx));
       const float mn = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f(m - mn);
       m = mn;
       float ps = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[r] = __builtin_amdgcn_exp2f(s[r] - mn);
-        ps += s[r];
-      }
+      for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[i][r] = __builtin_amdgcn_exp2f(s[i][r] - mn);
+          ps += s[i][r];
+        }
       lsum = lsum * alpha + ps;
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
-      if (drop) apply_drop(key0, s);  // after the row sum: the softmax is normalised over every key
-      second_product(sb, s);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        if constexpr (DROP) apply_drop(kb * AT_BLK + 32 * i, s[i]);  // after the row sum: the softmax is normalised over every key
+        second_product(i, s[i]);
+      }
+    };
+    stream_keys([&](int kb) {
+      if (kb * AT_BLK + 32 < N) step(std::integral_constant<int, 2>{}, kb);
+      else step(std::integral_constant<int, 1>{}, kb);
     });
   } else {
     auto dprobs = [&](int sb) -> f32x16 {
@@ -288,22 +308,26 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
     // pass 2.  (rowsum(dO * O) equals it in exact arithmetic, but O is stored rounded to bf16 and the
     // difference does not cancel in sum_m ds[n,m] k_m: it shows up as an error of dq proportional to |dO||O|.)
     float dacc = 0.f;
-    stream_keys([&](int sb, int key0) {
-      const f32x16 s = scores(sb);
-      f32x16 dp = dprobs(sb);
-      if (drop) apply_drop(key0, dp);  // d(prob) = mask/(1-p) * d(dropped prob)
+    stream_keys([&](int kb) {
+      each_sub(kb, [&](int sb, int key0) {
+        const f32x16 s = scores(sb);
+        f32x16 dp = dprobs(sb);
+        if constexpr (DROP) apply_drop(key0, dp);  // d(prob) = mask/(1-p) * d(dropped prob)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dacc += __builtin_amdgcn_exp2f(s[r] - l2) * dp[r];
+        for (int r = 0; r < 16; ++r) dacc += __builtin_amdgcn_exp2f(s[r] - l2) * dp[r];
+      });
     });
     dsum = dacc + xchg32(dacc);
     if (active && hh == 0 && q0 + j < N) a.dvec[((size_t)b * a.H + h) * N + q0 + j] = dsum;
-    stream_keys([&](int sb, int key0) {
-      f32x16 s = scores(sb);
-      f32x16 dp = dprobs(sb);
-      if (drop) apply_drop(key0, dp);
+    stream_keys([&](int kb) {
+      each_sub(kb, [&](int sb, int key0) {
+        f32x16 s = scores(sb);
+        f32x16 dp = dprobs(sb);
+        if constexpr (DROP) apply_drop(key0, dp);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - l2) * (dp[r] - dsum);
-      second_product(sb, s);
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] - l2) * (dp[r] - dsum);
+        second_product(sb, s);
+      });
     });
   }
   if (!active || q0 + j >= N) return;
@@ -318,7 +342,8 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnArgs a) {
 
 // ----------------------------------------------------------------------------------------------
 // dK / dV: a wave owns 32 keys, Q and dO stream through LDS in blocks of 64 queries.
-__global__ __launch_bounds__(256) void attn_kv_kernel(const AttnArgs a) {
+template <bool DROP>
+__global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_kv_kernel(const AttnArgs a) {
   __shared__ __align__(16) bf16_t Qr[AT_BLK * AT_PR];
   __shared__ __align__(16) bf16_t Qt[AT_BLK * AT_PT];
   __shared__ __align__(16) bf16_t Dr[AT_BLK * AT_PR];
@@ -351,9 +376,8 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(const AttnArgs a) {
   }
   float kbias = 0.f;
   if (a.key_bias != nullptr) kbias = fmaxf(a.key_bias[(size_t)b * N + krow], AT_MIN_BIAS) * AT_LOG2E;
-  const bool drop = a.drop_state != nullptr;  // uniform
   unsigned long long dseed = 0, dctr = 0;
-  if (drop) { dseed = a.drop_state[0]; dctr = a.drop_state[1]; }
+  if constexpr (DROP) { dseed = a.drop_state[0]; dctr = a.drop_state[1]; }
   const unsigned long long rowbase = ((unsigned long long)b * a.H + h) * N;
   const int dgroups = (N + 3) >> 2;
   const int krow_true = k0 + j;
@@ -412,7 +436,7 @@ __global__ __launch_bounds__(256) void attn_kv_kernel(const AttnArgs a) {
           for (int e = 0; e < 4; ++e) {
             const float p = __builtin_amdgcn_exp2f(s[4 * g + e] * c2 + kbias - lv[e]);
             float mk = 1.f;
-            if (drop) {  // the word of this lane's key in the call of the register's query row
+            if constexpr (DROP) {  // the word of this lane's key in the call of the register's query row
               const unsigned long long row = rowbase + (unsigned long long)(qb * AT_BLK + sb * 32 + 8 * g + 4 * hh + e);
               const Philox4 r = philox4x32_10(dseed, row * (unsigned long long)dgroups + (unsigned long long)(krow_true >> 2), dctr);
               const unsigned int w4[4] = {r.x, r.y, r.z, r.w};
@@ -692,7 +716,8 @@ extern "C" int vqaf_attn_fwd(const void* q, const void* k, const void* v, long l
   const int rd = attn_dropout(a, dropout_p, dropout_state);
   if (rd != VQAF_OK) return rd;
   const dim3 grid((N + AT_OWN - 1) / AT_OWN, H, B);
-  hipLaunchKernelGGL(attn_q_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (a.drop_state != nullptr) hipLaunchKernelGGL((attn_q_kernel<0, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((attn_q_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
   VQAF_LAUNCH_CHECK();
 }
 
@@ -717,8 +742,14 @@ extern "C" int vqaf_attn_bwd(const void* q, const void* k, const void* v, long l
   const int rd = attn_dropout(a, dropout_p, dropout_state);
   if (rd != VQAF_OK) return rd;
   const dim3 grid((N + AT_OWN - 1) / AT_OWN, H, B);
-  hipLaunchKernelGGL(attn_q_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);   // dQ, and the softmax row terms for the next launch
-  hipLaunchKernelGGL(attn_kv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  // dQ (and the softmax row terms for the next launch), then dK / dV
+  if (a.drop_state != nullptr) {
+    hipLaunchKernelGGL((attn_q_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_kv_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL((attn_q_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_kv_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   VQAF_LAUNCH_CHECK();
 }
 
