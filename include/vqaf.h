@@ -372,8 +372,8 @@ int vqaf_gemm_f32_atomic(const void* A, int a_dtype, long a_sg, long a_sm, long 
  *   dgrad    gx = gy W     : A = gy, B = W (out,in) k-major, C bf16
  *   clipped sum S = G^T A  : A = G (batch,out) k-major, B = A (batch,in) k-major, C f32, colsum =
  *                            sum_b G[b][m] (the bias gradient); rows of G already carry the clip factor.
- * A, B bf16; C f32 or bf16 (c_dtype); bias f32 or bf16 (bias_dtype) or NULL; accumulate != 0 adds
- * into an f32 C (and colsum).  Few output tiles with an f32 C split the contraction over workgroups
+ * A, B bf16; C f32 or bf16 (c_dtype); bias f32 or bf16 (bias_dtype) or NULL; colsum is f32 with either
+ * C; accumulate != 0 adds into an f32 C (and colsum).  Few output tiles with an f32 C split the contraction over workgroups
  * and add partial tiles with f32 atomics (summation order then varies from run to run).
  * vqaf_gemm_bf16_supported tells whether the layout is covered: row pitches multiples of 8
  * elements, a k-contiguous operand needs K % 8 == 0, a k-major operand needs its row pitch to

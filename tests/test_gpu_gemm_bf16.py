@@ -68,6 +68,13 @@ def test_gemm_bf16_layouts_and_edges(dev, layout, M, N, K):
     # accumulate adds a second product
     ops.gemm_bf16(A, ak, B, bk, M, N, K, C, accumulate=True, colsum=colsum)
     np.testing.assert_allclose(C.cpu().numpy(), 2 * want.numpy(), rtol=1e-5, atol=6e-6 * scale)
+    # bf16 output with the f32 column sums beside it (weight + bias gradient of an encoder Linear)
+    if ak:
+        Cb = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        colsum.fill_(float("nan"))
+        ops.gemm_bf16(A, ak, B, bk, M, N, K, Cb, colsum=colsum)
+        np.testing.assert_allclose(Cb.double().cpu().numpy(), want.numpy(), rtol=2 ** -8, atol=2 ** -8 * scale)
+        np.testing.assert_allclose(colsum.cpu().numpy(), cs.numpy(), rtol=1e-5, atol=3e-6 * float(cs.abs().max()))
     # bf16 output with a bias (what the forward uses); f32 bias and bf16 bias
     if not ak:
         bias = gi.normal(7, N)

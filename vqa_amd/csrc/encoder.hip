@@ -531,15 +531,19 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* x, const
 }
 
 // dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)) (+ ds_in);  dgamma = sum dy*xhat, dbeta = sum dy.
-// A workgroup takes LN_ROWS consecutive rows (one wave per row at a time) and writes its column sums
+// A workgroup takes rows_per_wg consecutive rows (two rows per wave at a time) and writes its column sums
 // to part[block][2][D]; layernorm_param_grad_kernel folds the blocks.  (Atomics onto the 2*D sums
 // were tried first: every workgroup hits the same addresses and the kernel ran at a fifth of its
 // memory-bound time.)
-constexpr int LN_ROWS = 32;
+// rows per workgroup: two workgroups per CU on a 256-CU part take the whole matrix in one round
+static inline int ln_rows_per_wg(long rows) {
+  const long r = (rows + 511) / 512;
+  return (int)(r < 8 ? 8 : r > 64 ? 64 : r);
+}
 template <bool BF16, bool PBF16, int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, const void* s, const void* gamma,
                                                             const float* mean, const float* rstd, const void* ds_in,
-                                                            long rows, int D, void* dx, float* part) {
+                                                            long rows, int D, int rows_per_wg, void* dx, float* part) {
   extern __shared__ float red[];  // [3][2][NCH*512]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float ag[NCH][8], ab[NCH][8];
@@ -553,45 +557,64 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, cons
     const int col = (c * 64 + lane) * 8;
     if (col < D) load8<PBF16>(gamma, col, g[c]);
   }
-  const long row_end = min(rows, ((long)blockIdx.x + 1) * LN_ROWS);
-  for (long row = (long)blockIdx.x * LN_ROWS + wave; row < row_end; row += 4) {
-    const size_t base = (size_t)row * D;
-    const float mu = mean[row], rs = rstd[row];
-    float dyv[NCH][8], xh[NCH][8];
-    float s1 = 0.f, s2 = 0.f;
+  // Two rows per wave are in flight (their loads are issued before either is reduced): with one, the
+  // kernel waited out a full memory latency per row and ran at half its bandwidth.
+  const long row_end = min(rows, ((long)blockIdx.x + 1) * rows_per_wg);
+  for (long row0 = (long)blockIdx.x * rows_per_wg + wave; row0 < row_end; row0 += 8) {
+    float dyv[2][NCH][8], xh[2][NCH][8], dsv[2][NCH][8];
+    float mu[2], rs[2];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = (c * 64 + lane) * 8;
-      if (col < D) {
-        load8<BF16>(dy, base + col, dyv[c]);
-        load8<BF16>(s, base + col, xh[c]);
+    for (int u = 0; u < 2; ++u) {
+      const long row = min(row0 + 4 * u, rows - 1);  // clamped: the second row may not exist
+      const size_t base = (size_t)row * D;
+      mu[u] = mean[row];
+      rs[u] = rstd[row];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xh[c][e] = (xh[c][e] - mu) * rs;
-          ag[c][e] += dyv[c][e] * xh[c][e];
-          ab[c][e] += dyv[c][e];
-          dyv[c][e] *= g[c][e];
-          s1 += dyv[c][e];
-          s2 += dyv[c][e] * xh[c][e];
+      for (int c = 0; c < NCH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < D) {
+          load8<BF16>(dy, base + col, dyv[u][c]);
+          load8<BF16>(s, base + col, xh[u][c]);
+          if (ds_in != nullptr) load8<BF16>(ds_in, base + col, dsv[u][c]);
         }
       }
     }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = (c * 64 + lane) * 8;
-      if (col < D) {
-        float o[8];
+    for (int u = 0; u < 2; ++u) {
+      const long row = row0 + 4 * u;
+      if (row >= row_end) break;
+      const size_t base = (size_t)row * D;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rs * (dyv[c][e] - s1 - xh[c][e] * s2);
-        if (ds_in != nullptr) {
-          float t[8];
-          load8<BF16>(ds_in, base + col, t);
+      for (int c = 0; c < NCH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < D) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += t[e];
+          for (int e = 0; e < 8; ++e) {
+            xh[u][c][e] = (xh[u][c][e] - mu[u]) * rs[u];
+            ag[c][e] += dyv[u][c][e] * xh[u][c][e];
+            ab[c][e] += dyv[u][c][e];
+            dyv[u][c][e] *= g[c][e];
+            s1 += dyv[u][c][e];
+            s2 += dyv[u][c][e] * xh[u][c][e];
+          }
         }
-        store8<BF16>(dx, base + col, o);
+      }
+      s1 = wave_sum(s1) / (float)D;
+      s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < D) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rs[u] * (dyv[u][c][e] - s1 - xh[u][c][e] * s2);
+          if (ds_in != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += dsv[u][c][e];
+          }
+          store8<BF16>(dx, base + col, o);
+        }
       }
     }
   }
@@ -765,9 +788,10 @@ void launch_ln_fwd(int nch, const void* x, const void* r, const void* gamma, con
 template <bool BF16, bool PBF16>
 void launch_ln_bwd(int nch, const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                    const void* ds_in, long rows, int D, void* dx, float* part, hipStream_t stream) {
-  const dim3 grid((unsigned)((rows + LN_ROWS - 1) / LN_ROWS));
+  const int rpw = ln_rows_per_wg(rows);
+  const dim3 grid((unsigned)((rows + rpw - 1) / rpw));
   const size_t lds = (size_t)3 * 2 * nch * 512 * sizeof(float);
-#define LN_BWD(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<BF16, PBF16, NCH>), grid, dim3(256), lds, stream, dy, s, gamma, mean, rstd, ds_in, rows, D, dx, part)
+#define LN_BWD(NCH) hipLaunchKernelGGL((layernorm_bwd_kernel<BF16, PBF16, NCH>), grid, dim3(256), lds, stream, dy, s, gamma, mean, rstd, ds_in, rows, D, rpw, dx, part)
   if (nch == 1) LN_BWD(1); else if (nch == 2) LN_BWD(2); else LN_BWD(4);
 #undef LN_BWD
 }
@@ -797,7 +821,8 @@ extern "C" int vqaf_layernorm_fwd(const void* x, const void* residual, const voi
 
 extern "C" size_t vqaf_layernorm_bwd_workspace_bytes(long rows, int D) {
   if (rows <= 0 || D <= 0) return 0;
-  return (size_t)((rows + LN_ROWS - 1) / LN_ROWS) * 2 * (size_t)D * sizeof(float);
+  const int rpw = ln_rows_per_wg(rows);
+  return (size_t)((rows + rpw - 1) / rpw) * 2 * (size_t)D * sizeof(float);
 }
 
 extern "C" int vqaf_layernorm_bwd(const void* dy, const void* s, const void* gamma, int param_dtype,
@@ -821,7 +846,8 @@ extern "C" int vqaf_layernorm_bwd(const void* dy, const void* s, const void* gam
     if (param_dtype == VQAF_BF16) launch_ln_bwd<false, true>(nch, dy, s, gamma, mean, rstd, dsum_in, rows, D, dx, part, st);
     else launch_ln_bwd<false, false>(nch, dy, s, gamma, mean, rstd, dsum_in, rows, D, dx, part, st);
   }
-  const int nblk = (int)((rows + LN_ROWS - 1) / LN_ROWS);
+  const int rpw = ln_rows_per_wg(rows);
+  const int nblk = (int)((rows + rpw - 1) / rpw);
   const dim3 grid((2 * D + 15) / 16);
   if (param_dtype == VQAF_BF16) hipLaunchKernelGGL(layernorm_param_grad_kernel<true>, grid, dim3(256), 0, st, part, nblk, D, dgamma, dbeta);
   else hipLaunchKernelGGL(layernorm_param_grad_kernel<false>, grid, dim3(256), 0, st, part, nblk, D, dgamma, dbeta);

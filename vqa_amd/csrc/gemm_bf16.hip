@@ -430,7 +430,7 @@ extern "C" int vqaf_gemm_bf16(const void* A, long lda, int a_kmajor, const void*
   VQAF_REQUIRE(M > 0 && N > 0 && K > 0 && ldc >= N, VQAF_E_SHAPE);
   VQAF_REQUIRE(vqaf_gemm_bf16_supported(lda, a_kmajor, ldb, b_kmajor, M, N, K), VQAF_E_ALIGN);
   VQAF_REQUIRE(vqaf_aligned16(A) && vqaf_aligned16(B), VQAF_E_ALIGN);
-  VQAF_REQUIRE(!(c_dtype == VQAF_BF16 && (accumulate || colsum != nullptr)), VQAF_E_DTYPE);
+  VQAF_REQUIRE(!(c_dtype == VQAF_BF16 && accumulate), VQAF_E_DTYPE);
   VQAF_REQUIRE(colsum == nullptr || a_kmajor, VQAF_E_SHAPE);
   const unsigned int* zeros = nullptr;
   const int rc = zero_block_on_current_device(&zeros);

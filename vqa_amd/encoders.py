@@ -191,10 +191,14 @@ class _LinearFn(torch.autograd.Function):
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if ops.gemm_bf16_supported(out_f, True, in_f, True, out_f, in_f, T):
-                gw32 = torch.empty(out_f, in_f, dtype=torch.float32, device=x.device)
+                # An f32 output lets the kernel split the contraction over workgroups when the output has
+                # too few tiles to fill the chip; enough tiles (>= 192 of 128 x 64) go straight to bf16.
+                direct = ((out_f + 127) // 128) * ((in_f + 63) // 64) >= 192
+                gw = torch.empty(out_f, in_f, dtype=torch.bfloat16 if direct else torch.float32, device=x.device)
                 cs = torch.empty(out_f, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-                ops.gemm_bf16(gy2, True, x2, True, out_f, in_f, T, gw32, colsum=cs)
-                gw = gw32.to(w.dtype)
+                ops.gemm_bf16(gy2, True, x2, True, out_f, in_f, T, gw, colsum=cs)
+                if not direct:
+                    gw = gw.to(w.dtype)
                 gb = None if cs is None else cs.to(ctx.bdtype)
             else:  # row pitches the kernel does not cover (not multiples of 8): library GEMM
                 gw = torch.mm(gy2.t(), x2)
