@@ -301,3 +301,55 @@ def test_full_size_encoders_batch8_against_oracle():
     assert _rel(v_seq, rv_seq) < 1.5e-2 and _rel(v_glob, rv_glob) < 1.5e-2
     live = mask.bool()
     assert _rel(q_seq[live.to(DEV)], rq_seq[live]) < 1.5e-2 and _rel(q_glob, rq_glob) < 1.5e-2
+
+
+@pytest.mark.parametrize("pruning", [False, True])
+def test_whole_model_with_encoders_matches_the_composed_oracle(pruning):
+    """VQAModel(ViT, Bert, co_attention) in eval mode, batch 8, 224 px / 30 tokens, against the host composition
+    encoder oracle -> projections -> fusion oracle -> classifier (all f32).  The pruning variant may differ in
+    a keep index where two attention weights tie within bf16 noise; the logits are compared, with a looser bar."""
+    from oracle import fusion_oracle as fo
+    from vqa_amd import model as vm
+
+    def vit_cls(out_features=512):
+        return encoders.ViT(out_features=out_features, config=encoders.ViTConfig(
+            hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=512, image_size=224))
+
+    def bert_cls(hidden_dim=512):
+        return encoders.Bert(hidden_dim=hidden_dim, config=encoders.BertConfig(
+            hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=512, vocab_size=500,
+            max_position_embeddings=64))
+
+    torch.manual_seed(7)
+    m = vm.VQAModel(vit_cls, bert_cls, fusion_type="co_attention", num_classes=13, use_token_pruning=pruning,
+                    prune_ratio=0.5, adversarial_mix=False, noise_injection=False).eval()
+    with torch.no_grad():
+        for p in m.vision_encoder.vit.parameters():
+            p.copy_(torch.randn_like(p) * 0.06)
+        for p in m.text_encoder.bert.parameters():
+            p.copy_(torch.randn_like(p) * 0.06)
+    imgs = torch.randn(8, 3, 224, 224)
+    ids = torch.randint(1, 500, (8, 30))
+    mask = torch.ones(8, 30, dtype=torch.long)
+    F = torch.nn.functional
+    with torch.no_grad():
+        ve, te, fm = m.vision_encoder, m.text_encoder, m.fusion_module
+        h, pooled = eo.vit_forward(ve.vit.state_dict(), imgs, heads=4, patch=16)
+        v_seq, v_glob = F.linear(h, ve.seq_projection.weight, ve.seq_projection.bias), \
+            F.linear(pooled, ve.global_projection.weight, ve.global_projection.bias)
+        h, pooled = eo.bert_forward(te.bert.state_dict(), ids, mask, heads=4)
+        q_seq, q_glob = F.linear(h, te.seq_projection.weight, te.seq_projection.bias), \
+            F.linear(pooled, te.global_projection.weight, te.global_projection.bias)
+        t2v, v2t = fm.txt_to_vis_attn, fm.vis_to_txt_attn
+        if pruning:
+            fused, _, _ = fo.co_attention_pruned(v_seq, v_glob, q_seq, q_glob, (t2v.in_proj_weight, t2v.in_proj_bias),
+                                                 (v2t.in_proj_weight, v2t.in_proj_bias), adversarial_mix=False)
+        else:
+            fused = fo.co_attention_dense(v_seq, v_glob, q_seq, q_glob,
+                                          (t2v.in_proj_weight, t2v.in_proj_bias, t2v.out_proj.weight, t2v.out_proj.bias),
+                                          (v2t.in_proj_weight, v2t.in_proj_bias, v2t.out_proj.weight, v2t.out_proj.bias))
+        want = m.classifier(fused)
+        m.to(DEV)
+        got = m(imgs.to(DEV), ids.to(DEV), mask.to(DEV))
+    assert got.shape == (8, 13)
+    assert _rel(got, want) < (6e-2 if pruning else 3e-2), _rel(got, want)

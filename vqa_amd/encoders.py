@@ -585,7 +585,8 @@ class ViT(nn.Module):
 
     def forward(self, images):
         h, pooled = self.vit(images)
-        return _linear(h, self.seq_projection), _linear(pooled, self.global_projection)
+        dt = self.seq_projection.weight.dtype  # the stack computes in bf16; results leave in the parameters' dtype
+        return _linear(h, self.seq_projection).to(dt), _linear(pooled, self.global_projection).to(dt)
 
 
 class Bert(nn.Module):
@@ -608,4 +609,5 @@ class Bert(nn.Module):
 
     def forward(self, input_ids, attention_mask):
         h, pooled = self.bert(input_ids, attention_mask)
-        return _linear(h, self.seq_projection), _linear(pooled, self.global_projection)
+        dt = self.seq_projection.weight.dtype
+        return _linear(h, self.seq_projection).to(dt), _linear(pooled, self.global_projection).to(dt)
