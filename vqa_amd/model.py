@@ -7,6 +7,7 @@ Sequential of model/model.py:54-63 (the DP-SGD target, see vqa_amd.dp).
 """
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 
 from .fusion import Attention, CoAttention, Concat
@@ -42,11 +43,35 @@ class VQAModel(nn.Module):
             nn.Linear(hidden_dim * 2, hidden_dim), nn.BatchNorm1d(hidden_dim), nn.ReLU(),
             nn.Linear(hidden_dim, num_classes))
 
+    # Run the two encoders on two HIP streams: they are independent until the fusion, and the text
+    # encoder's kernels (30 tokens per sample) are far too small to fill the GPU, so they fit into what
+    # the vision encoder's leave idle.  autograd replays each node on the stream its forward ran on, so the
+    # two backward passes overlap the same way.  Results are those of the sequential order.
+    overlap_encoders = True
+
     def forward(self, images, input_ids, attention_mask):
-        v_seq, v_global = self.vision_encoder(images)
-        q_seq, q_global = self.text_encoder(input_ids, attention_mask)
+        if self.overlap_encoders and images.is_cuda:
+            main = torch.cuda.current_stream(images.device)
+            side = self._side_stream(images.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                q_seq, q_global = self.text_encoder(input_ids, attention_mask)
+            v_seq, v_global = self.vision_encoder(images)
+            main.wait_stream(side)
+            for t in (q_seq, q_global):
+                t.record_stream(main)  # allocated on the side stream, consumed on this one
+        else:
+            v_seq, v_global = self.vision_encoder(images)
+            q_seq, q_global = self.text_encoder(input_ids, attention_mask)
         fused = self.fusion_module(v_seq, v_global, q_seq, q_global)
         return self.classifier(fused)
+
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            self._side = st
+        return st
 
 
 def load_weights(model: nn.Module, state_dict: dict) -> nn.Module:
