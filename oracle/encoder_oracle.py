@@ -56,10 +56,16 @@ def vit_forward(sd, images, heads, patch, eps=1e-12):
     return x, pooled
 
 
-def bert_forward(sd, input_ids, attention_mask, heads, eps=1e-12):
-    """BertModel.forward in eval mode, token_type_ids = 0, absolute positions."""
+def bert_forward(sd, input_ids, attention_mask, heads, eps=1e-12, roberta_pad=None):
+    """BertModel.forward in eval mode, token_type_ids = 0, absolute positions.  roberta_pad = the padding
+    index selects RobertaModel's embeddings (`modeling_roberta.py`: create_position_ids_from_input_ids)."""
     L = input_ids.shape[1]
-    x = (sd["embeddings.word_embeddings.weight"][input_ids] + sd["embeddings.position_embeddings.weight"][:L]
+    if roberta_pad is None:
+        pos = sd["embeddings.position_embeddings.weight"][:L]
+    else:
+        live = (input_ids != roberta_pad).long()
+        pos = sd["embeddings.position_embeddings.weight"][torch.cumsum(live, 1) * live + roberta_pad]
+    x = (sd["embeddings.word_embeddings.weight"][input_ids] + pos
          + sd["embeddings.token_type_embeddings.weight"][0])
     E = x.shape[-1]
     x = F.layer_norm(x, (E,), sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"], eps)

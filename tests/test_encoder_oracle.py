@@ -74,6 +74,34 @@ def test_bert_oracle_reproduces_transformers_with_padding():
     torch.testing.assert_close(pooled, ref.pooler_output, rtol=1e-5, atol=1e-6)
 
 
+def test_roberta_oracle_reproduces_transformers_with_padding():
+    torch.manual_seed(2)
+    cfg = transformers.RobertaConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                                     vocab_size=97, max_position_embeddings=40, type_vocab_size=1, pad_token_id=1,
+                                     layer_norm_eps=1e-5)
+    m = transformers.RobertaModel(cfg).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * 0.05)
+    ids = torch.randint(2, 97, (4, 11))
+    mask = torch.ones(4, 11, dtype=torch.long)
+    mask[1, 7:] = 0
+    ids[1, 7:] = 1
+    with torch.no_grad():
+        ref = m(input_ids=ids, attention_mask=mask)
+        h, pooled = eo.bert_forward(m.state_dict(), ids, mask, heads=2, eps=1e-5, roberta_pad=1)
+    torch.testing.assert_close(h, ref.last_hidden_state, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pooled, ref.pooler_output, rtol=1e-5, atol=1e-6)
+    mine = encoders.BertModel(encoders.roberta_config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                                      intermediate_size=256, vocab_size=97, max_position_embeddings=40))
+    want = {k: tuple(v.shape) for k, v in m.state_dict().items() if "position_ids" not in k and "token_type_ids" not in k}
+    assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == want
+    wrapper = encoders.RoBerta(hidden_dim=64, config=encoders.roberta_config(
+        hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, vocab_size=97,
+        max_position_embeddings=40))
+    assert wrapper.output_dim == 64 and wrapper.bert.config.roberta_positions
+
+
 def test_module_parameter_names_are_the_checkpoint_names():
     cfg, m = _tiny_vit()
     want = {k: tuple(v.shape) for k, v in _vit_keys_to_pinned(m.state_dict()).items()}

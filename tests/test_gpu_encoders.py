@@ -353,3 +353,23 @@ def test_whole_model_with_encoders_matches_the_composed_oracle(pruning):
         got = m(imgs.to(DEV), ids.to(DEV), mask.to(DEV))
     assert got.shape == (8, 13)
     assert _rel(got, want) < (6e-2 if pruning else 3e-2), _rel(got, want)
+
+
+def test_roberta_stack_matches_oracle_with_padding():
+    torch.manual_seed(3)
+    cfg = encoders.roberta_config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                                  vocab_size=101, max_position_embeddings=40)
+    m = encoders.BertModel(cfg).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * 0.08)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ids = torch.randint(2, 101, (3, 20))
+    mask = torch.ones(3, 20, dtype=torch.long)
+    mask[2, 9:] = 0
+    ids[2, 9:] = 1
+    with torch.no_grad():
+        rh, rp = eo.bert_forward(sd, ids, mask, heads=2, eps=1e-5, roberta_pad=1)
+        h, pooled = m.to(DEV)(ids.to(DEV), mask.to(DEV))
+    live = mask.bool()
+    assert _rel(h[live.to(DEV)], rh[live]) < 1e-2 and _rel(pooled, rp) < 1e-2

@@ -263,12 +263,25 @@ class BertConfig:
     attention_probs_dropout_prob: float = 0.1
     pad_token_id: int = 0
     initializer_range: float = 0.02
+    # RoBERTa numbers positions from pad_token_id + 1 and skips padding tokens (model_type "roberta")
+    roberta_positions: bool = False
+
+
+def roberta_config(**kw) -> "BertConfig":
+    """roberta-base shape: the BERT stack with 50265 tokens, 514 positions counted from the padding index,
+    one token type and LayerNorm eps 1e-5."""
+    base = dict(vocab_size=50265, max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5,
+                pad_token_id=1, roberta_positions=True)
+    base.update(kw)
+    return BertConfig(**base)
 
 
 def _config_from_json(cls, path):
     with open(path) as f:
         raw = json.load(f)
     fields = {k: raw[k] for k in cls.__dataclass_fields__ if k in raw}
+    if cls is BertConfig and raw.get("model_type") == "roberta":
+        fields["roberta_positions"] = True
     return cls(**fields)
 
 
@@ -442,10 +455,16 @@ class _BertEmbeddings(nn.Module):
         self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, E)
         self.LayerNorm = nn.LayerNorm(E, eps=cfg.layer_norm_eps)
         self.eps, self.p = cfg.layer_norm_eps, cfg.hidden_dropout_prob
+        self.pad, self.roberta = cfg.pad_token_id, cfg.roberta_positions
 
     def forward(self, input_ids, dtype):
         L = input_ids.shape[1]
-        pos = self.position_embeddings.weight[:L] + self.token_type_embeddings.weight[0]
+        if self.roberta:
+            # RobertaEmbeddings: position = pad + (1-based index among the non-padding tokens), pad for padding
+            live = (input_ids != self.pad).to(torch.long)
+            pos = self.position_embeddings(torch.cumsum(live, 1) * live + self.pad) + self.token_type_embeddings.weight[0]
+        else:
+            pos = self.position_embeddings.weight[:L] + self.token_type_embeddings.weight[0]
         x = (self.word_embeddings(input_ids) + pos).to(dtype)
         y, _ = add_layer_norm(x, None, self.LayerNorm.weight, self.LayerNorm.bias, self.eps)
         return F.dropout(y, self.p, self.training)
@@ -539,9 +558,9 @@ def _read_state(path: str) -> dict:
     return torch.load(path, map_location="cpu", weights_only=True)
 
 
-def load_checkpoint(model: nn.Module, path: str, prefixes=("vit.", "bert.")) -> nn.Module:
+def load_checkpoint(model: nn.Module, path: str, prefixes=("vit.", "bert.", "roberta.")) -> nn.Module:
     """Loads a locally stored Hugging Face checkpoint of the same architecture into `model`.
-    Task-head prefixes (`vit.`, `bert.`) are stripped; LayerNorm `gamma`/`beta` (old TF-converted BERT
+    Task-head prefixes (`vit.`, `bert.`, `roberta.`) are stripped; LayerNorm `gamma`/`beta` (old TF-converted BERT
     files) are renamed; tensors the model does not have (`cls.*`, `classifier.*`, `position_ids`) are
     ignored; a tensor the model has but the file lacks is an error."""
     raw = _read_state(path)
@@ -611,3 +630,14 @@ class Bert(nn.Module):
         h, pooled = self.bert(input_ids, attention_mask)
         dt = self.seq_projection.weight.dtype
         return _linear(h, self.seq_projection).to(dt), _linear(pooled, self.global_projection).to(dt)
+
+
+class RoBerta(Bert):
+    """The reference's `RoBerta` wrapper (model/text_encoder.py:51-89): the same contract and the same
+    attribute names (`self.bert` holds the stack), on a roberta-base-shaped encoder."""
+
+    def __init__(self, model_name: str | None = None, hidden_dim: int = 512, config: BertConfig | None = None,
+                 compute_dtype=torch.bfloat16):
+        if config is None and not (model_name is not None and os.path.exists(os.path.join(model_name, "config.json"))):
+            config = roberta_config()
+        super().__init__(model_name, hidden_dim, config, compute_dtype)
