@@ -50,9 +50,9 @@ class VQAModel(nn.Module):
     overlap_encoders = True
 
     def forward(self, images, input_ids, attention_mask):
-        if self.overlap_encoders and images.is_cuda:
+        side = self._side_stream(images.device) if (self.overlap_encoders and images.is_cuda) else None
+        if side is not None:
             main = torch.cuda.current_stream(images.device)
-            side = self._side_stream(images.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 q_seq, q_global = self.text_encoder(input_ids, attention_mask)
@@ -66,12 +66,20 @@ class VQAModel(nn.Module):
         fused = self.fusion_module(v_seq, v_global, q_seq, q_global)
         return self.classifier(fused)
 
-    def _side_stream(self, device):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != device:
+    @staticmethod
+    def _side_stream(device):
+        """The second stream of `device`, shared by every model (kept outside the module so that copying or
+        pickling a model never meets a stream object)."""
+        st = _SIDE_STREAMS.get(device.index)
+        if st is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None  # a stream cannot be created while a graph is captured: sequential order this time
             st = torch.cuda.Stream(device=device)
-            self._side = st
+            _SIDE_STREAMS[device.index] = st
         return st
+
+
+_SIDE_STREAMS: dict = {}
 
 
 def load_weights(model: nn.Module, state_dict: dict) -> nn.Module:
