@@ -639,7 +639,7 @@ def main():
         if not args.no_sweep:
             line["prune_mix_cfg4"] = prune_mix_sweep(dev, dtype)
             line["dense_branch"] = dense_leg(dev, dtype)
-        if not args.no_full_model and dtype == torch.bfloat16:
+        if not args.no_full_model and dtype == torch.bfloat16 and world == 1:  # a one-GPU measurement
             line["full_model_cfg2"] = full_model_leg(dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
