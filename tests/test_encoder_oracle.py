@@ -161,3 +161,18 @@ def test_encoders_refuse_cpu_tensors():
                                                                   vocab_size=50, max_position_embeddings=16))
     with pytest.raises(RuntimeError, match="GPU only"):
         enc(torch.randint(1, 50, (2, 5)), torch.ones(2, 5, dtype=torch.long))
+
+
+def test_local_checkpoint_import_vit_torch_file(tmp_path):
+    """A `pytorch_model.bin` task checkpoint (`vit.` prefix, a classifier head) read with weights_only=True."""
+    cfg, m = _tiny_vit(seed=5)
+    d = tmp_path / "vit-tiny"
+    d.mkdir()
+    sd = {"vit." + k: v.clone() for k, v in _vit_keys_to_pinned(m.state_dict()).items()}
+    sd["classifier.weight"] = torch.zeros(10, 128)
+    torch.save(sd, str(d / "pytorch_model.bin"))
+    (d / "config.json").write_text(cfg.to_json_string())
+    enc = encoders.ViT(model_name=str(d), out_features=64)
+    assert enc.vit.config.image_size == 48 and enc.vit.config.num_hidden_layers == 2
+    for k, v in _vit_keys_to_pinned(m.state_dict()).items():
+        assert torch.equal(enc.vit.state_dict()[k], v), k
