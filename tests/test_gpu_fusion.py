@@ -554,3 +554,31 @@ def test_multi_branch_launches_equal_single_branch_calls(dev):
             hs = ops.head_score_matrix(sp["q"], sp["seq"], sp["in_proj_weight"], sp["in_proj_bias"], H)
             r = ops.select_indices(sp["k"], scores=hs, k_adv=sp["k_adv"], pos=sp["pos"], src=sp["src"])
             assert torch.equal(got, r["top"])
+
+
+@pytest.mark.parametrize("name", _names("coattn_"))
+def test_reference_order_scoring_mode(dev, name):
+    """score_order = "reference": the weights come from the MHA's own operation order (every key projected
+    first); keep indices and fused features equal the golden ones, and the weights sit closer to the
+    reference's than the folded form's tolerance."""
+    from vqa_amd import fusion
+    g = load_golden(name)
+    seed, B, N = int(g["seed"]), int(g["B"]), int(g["N"])
+    v_seq, v_global = gi.tokens(seed, B, N)
+    q_seq, q_global = gi.tokens(seed + 1, B, 30)
+    m = fusion.CoAttention(use_pruning=True, adversarial_mix=False, noise_injection=False)
+    m.txt_to_vis_attn.load_state_dict(gi.mha_params(seed + 2))
+    m.vis_to_txt_attn.load_state_dict(gi.mha_params(seed + 6))
+    m = m.to(dev)
+    m.score_order = "reference"
+    fused = m(v_seq.to(dev), v_global.to(dev), q_seq.to(dev), q_global.to(dev))
+    assert np.array_equal(m.v_pruning.last_indices.cpu().numpy(), g["v_idx"])
+    assert np.array_equal(m.q_pruning.last_indices.cpu().numpy(), g["q_idx"])
+    np.testing.assert_allclose(fused.detach().cpu().numpy(), g["fused"], rtol=F32_RTOL, atol=F32_ATOL)
+    p = gi.mha_params(seed + 2)
+    want = fo.attention_weights(q_global, v_seq, p["in_proj_weight"], p["in_proj_bias"], 8).reshape(B, N)
+    got = fusion._scores_reference_order(m.txt_to_vis_attn, q_global.to(dev), v_seq.to(dev)).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=4e-6, atol=1e-9)
+    m.score_order = "else"
+    with pytest.raises(ValueError):
+        m(v_seq.to(dev), v_global.to(dev), q_seq.to(dev), q_global.to(dev))

@@ -19,8 +19,11 @@ from __future__ import annotations
 
 from typing import Optional
 
+import math
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 
@@ -142,6 +145,29 @@ def _scores(mha: nn.MultiheadAttention, query: torch.Tensor, seq: torch.Tensor) 
     return ops.attention_scores(query, seq, mha.in_proj_weight, mha.in_proj_bias, mha.num_heads)
 
 
+@torch.no_grad()
+def _scores_reference_order(mha: nn.MultiheadAttention, query: torch.Tensor, seq: torch.Tensor) -> torch.Tensor:
+    """The same weights computed in the operation order of nn.MultiheadAttention itself
+    (torch.nn.functional.multi_head_attention_forward as called at utils/fusion.py:234-238): every token is
+    projected to its key first (one (2E)-wide in-projection GEMM for key and value), the query is scaled by
+    sqrt(1/dh), scores by bmm, softmax, mean over heads.  The kernels fold the query into the key projection
+    instead, which is equal in exact arithmetic and differs in the last bits; this form spends the
+    2*N*E*2E flops per sample of the projection to rank tokens exactly as the reference formulation does
+    (`score_order = "reference"` on the fusion modules).  f32 library GEMMs on the GPU; forward only."""
+    B, N, E = seq.shape
+    H = mha.num_heads
+    dh = E // H
+    w_q, w_kv = mha.in_proj_weight.split([E, 2 * E])
+    b_q, b_kv = mha.in_proj_bias.split([E, 2 * E])
+    q = F.linear(query.float().reshape(B, 1, E).transpose(0, 1), w_q.float(), b_q.float())
+    kv = F.linear(seq.float().transpose(0, 1), w_kv.float(), b_kv.float())
+    k = kv.unflatten(-1, (2, E))[..., 0, :].contiguous()
+    q = q.reshape(1, B * H, dh).transpose(0, 1)
+    k = k.reshape(N, B * H, dh).transpose(0, 1)
+    scores = torch.bmm(q * math.sqrt(1.0 / float(dh)), k.transpose(-2, -1))
+    return torch.softmax(scores, dim=-1).view(B, H, 1, N).mean(dim=1).reshape(B, N)
+
+
 def _head_scores(mha: nn.MultiheadAttention, query: torch.Tensor, seq: torch.Tensor) -> torch.Tensor:
     """Raw per-head scores (B,N,H); their softmax / head mean is fused into the selection kernel."""
     return ops.head_score_matrix(query, seq, mha.in_proj_weight, mha.in_proj_bias, mha.num_heads)
@@ -158,6 +184,7 @@ class Attention(nn.Module):
         self.use_pruning = use_pruning
         self.fuse_pool = True  # skip materialising the pruned tokens (same result)
         self.fuse_select = True  # scoring + selection + pooling of a sample in one workgroup (bf16 tokens)
+        self.score_order = "fold"  # "reference": rank tokens with the reference's own operation order
         if use_pruning:
             # utils/fusion.py:141-146 passes no noise arguments, so the class defaults apply
             # (noise_injection=True, noise_scale=0.01, gaussian).
@@ -166,7 +193,12 @@ class Attention(nn.Module):
 
     def forward(self, v_seq, v_global, q_seq, q_global, **inject):
         ops.require_gpu(v_seq)  # no CPU fallback: fail before anything else is touched
-        if self.use_pruning:
+        if self.use_pruning and self.score_order == "reference":
+            w = _scores_reference_order(self.attention, q_global, v_seq)
+            attended_v = ops.mean_pool(self.pruning(v_seq, w, **inject))
+        elif self.use_pruning:
+            if self.score_order != "fold":
+                raise ValueError(f"score_order must be 'fold' or 'reference', got {self.score_order!r}")
             spec = None
             if self.fuse_pool and self.fuse_select:
                 k, k_adv = self.pruning.plan(v_seq.shape[1])
@@ -210,6 +242,7 @@ class CoAttention(nn.Module):
         self.use_pruning = use_pruning
         self.fuse_pool = True
         self.fuse_select = True  # scoring + selection + pooling of a sample in one workgroup (bf16 tokens)
+        self.score_order = "fold"  # "reference": rank tokens with the reference's own operation order
         if use_pruning:
             self.v_pruning = PrivacyAwareTokenPruning(
                 prune_ratio=prune_ratio, mixup_alpha=mixup_alpha, adversarial_mix=adversarial_mix,
@@ -227,6 +260,14 @@ class CoAttention(nn.Module):
         q_inject = q_inject or {}
         ops.require_gpu(v_seq, q_seq)  # no CPU fallback: fail before anything else is touched
         if self.use_pruning:
+            if self.score_order == "reference":
+                v_w = _scores_reference_order(self.txt_to_vis_attn, q_global, v_seq)
+                q_w = _scores_reference_order(self.vis_to_txt_attn, v_global, q_seq)
+                attended_v = ops.mean_pool(self.v_pruning(v_seq, v_w, **v_inject))
+                attended_q = ops.mean_pool(self.q_pruning(q_seq, q_w, **q_inject))
+                return torch.cat([attended_v, attended_q.to(attended_v.dtype)], dim=1)
+            if self.score_order != "fold":
+                raise ValueError(f"score_order must be 'fold' or 'reference', got {self.score_order!r}")
             if self.fuse_pool:
                 # Both branches go through the same four launches (query folds x2, token scoring,
                 # selection); they draw from one counter with different salts, advanced once.
