@@ -285,6 +285,69 @@ def dense_leg(dev, dtype):
     return out
 
 
+def transformers_encoders_ms(dev, vqa_model, imgs, ids, mask, y):
+    """The same model and step with the two encoder stacks taken from the `transformers` package (what
+    model/vision_encoder.py:97 and model/text_encoder.py:21 construct), eager launches, same GPU: the
+    reference's own encoder path beside ours.  None when the package is not importable."""
+    os.environ.setdefault("HF_HUB_OFFLINE", "1")
+    try:
+        import transformers
+    except Exception:
+        return None
+    from vqa_amd import ops
+
+    class _Vision(nn.Module):
+        def __init__(self, out_features=512):
+            super().__init__()
+            self.vit = transformers.ViTModel(transformers.ViTConfig(), add_pooling_layer=True)
+            self.seq_projection = nn.Linear(768, out_features)
+            self.global_projection = nn.Linear(768, out_features)
+            self.output_dim = out_features
+
+        def forward(self, x):
+            o = self.vit(pixel_values=x)
+            return self.seq_projection(o.last_hidden_state), self.global_projection(o.pooler_output)
+
+    class _Text(nn.Module):
+        def __init__(self, hidden_dim=512):
+            super().__init__()
+            self.bert = transformers.BertModel(transformers.BertConfig())
+            self.seq_projection = nn.Linear(768, hidden_dim)
+            self.global_projection = nn.Linear(768, hidden_dim)
+            self.output_dim = hidden_dim
+
+        def forward(self, i, m):
+            o = self.bert(input_ids=i, attention_mask=m)
+            return self.seq_projection(o.last_hidden_state), self.global_projection(o.pooler_output)
+
+    try:
+        torch.manual_seed(0)
+        m = vqa_model.VQAModel(_Vision, _Text, fusion_type="co_attention", num_classes=C, use_token_pruning=True,
+                               prune_ratio=0.5).to(dev).to(torch.bfloat16).train()
+        m.overlap_encoders = False  # the reference runs them one after the other
+        params = list(m.parameters())
+
+        def fb():
+            for p in params:
+                p.grad = None
+            loss = ops.cross_entropy_mean(m(imgs, ids, mask), y)
+            loss.backward(gradient=ops.unit_gradient(loss))
+
+        for _ in range(3):
+            fb()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fb()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 10
+    except Exception as exc:  # a reference-side failure must not take the benchmark line with it
+        print(f"[bench] transformers encoder leg skipped ({type(exc).__name__}: {exc})", file=sys.stderr)
+        return None
+
+
 def full_model_leg(dev):
     """BASELINE configs[1]: the whole model (ViT-B/16 at 224 px + BERT-base at 30 tokens, CoAttention with
     token pruning at keep ratio 0.5, the classifier), forward + backward, batch 64, bf16 parameters and
@@ -348,7 +411,12 @@ def full_model_leg(dev):
         attn = 4.0 * T * N * E * LAYERS
         flops += 3.0 * gemm + 3.5 * attn
     del graph
-    return {"workload": "ViT-B/16 (224 px) + BERT-base (30 tokens) + CoAttention keep 0.5 + classifier, fwd+bwd, "
+    ref_ms = transformers_encoders_ms(dev, vqa_model, imgs, ids, mask, y)
+    out_extra = {} if ref_ms is None else {
+        "transformers_encoders_ms_fwd_bwd_eager": round(ref_ms, 3),
+        "speedup_vs_transformers_encoders": round(ref_ms / ms_eager, 3)}
+    return {**out_extra,
+            "workload": "ViT-B/16 (224 px) + BERT-base (30 tokens) + CoAttention keep 0.5 + classifier, fwd+bwd, "
                         "batch 64, bf16, non-private, random init",
             "ms_fwd_bwd": round(ms, 3), "ms_fwd_bwd_eager": round(ms_eager, 3), "launch": launch,
             "samples/s": round(B / ms * 1e3, 1), "encoder_TFLOP/s": round(flops / ms / 1e9, 1),
