@@ -677,10 +677,11 @@ def main():
         for name in sorted(probe.pairs):
             if not name.startswith("clipped_sum_linear:"):
                 continue
-            out_f, in_f = (int(v) for v in name.split(":")[1].split("x"))
+            shapes = [tuple(int(v) for v in part.split("x")) for part in name.split(":")[1].split("+")]
             ms = probe.mean_ms(name)
-            tf = 2.0 * local_b * out_f * in_f / ms / 1e9 if ms > 0 else 0.0
-            mfma.append({"kernel": f"clipped_sum_linear {out_f}x{in_f} over batch {local_b}", "ms": round(ms, 5),
+            tf = sum(2.0 * local_b * o * i for o, i in shapes) / ms / 1e9 if ms > 0 else 0.0
+            label = " + ".join(f"{o}x{i}" for o, i in shapes) + (" (one launch)" if len(shapes) > 1 else "")
+            mfma.append({"kernel": f"clipped_sum_linear {label} over batch {local_b}", "ms": round(ms, 5),
                          "tflops": round(tf, 1), "frac_of_2.5PF": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)})
         line = {
             "metric": "DP-SGD train samples/s (fusion+classifier+DP step, token-level inputs)",

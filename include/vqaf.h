@@ -383,6 +383,16 @@ int vqaf_gemm_bf16(const void* A, long lda, int a_kmajor, const void* B, long ld
                    int K, const void* bias, int bias_dtype, void* C, long ldc, int c_dtype, int accumulate,
                    float* colsum, vqaf_stream_t stream);
 
+/* n <= 4 products of the clipped-sum shape in ONE launch: C_i (M_i,N_i) f32 = A_i^T B_i with A_i (K,M_i) and
+ * B_i (K,N_i) bf16, both k-major, the same K (the batch); colsum (array of n pointers, or NULL, entries may be
+ * NULL) receives the column sums of A_i; accumulate != 0 adds into C_i / colsum_i.  The clipped sums of the
+ * classifier's Linear layers are launch-bound on their own.  Returns VQAF_E_SHAPE when a product has fewer than
+ * 192 output tiles (it wants its contraction split) or the products need different tile heights: the caller
+ * then uses vqaf_gemm_bf16 per product. */
+int vqaf_gemm_bf16_wgrad_group(int n, const void* const* A, const long* lda, const void* const* B,
+                               const long* ldb, const int* M, const int* N, int K, float* const* C,
+                               const long* ldc, int accumulate, float* const* colsum, vqaf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * DP-SGD step for the classifier.  The reference delegates this to Opacus 1.4.0
  * (GradSampleModule hooks + DPOptimizer.clip_and_accumulate / add_noise / scale_grad),

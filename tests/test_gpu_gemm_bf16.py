@@ -90,3 +90,41 @@ def test_gemm_bf16_rejects_uncovered_layouts(dev):
     assert not ops.gemm_bf16_supported(430, True, 1024, True, 430, 1024, 1024)   # row pitch not a multiple of 8
     assert not ops.gemm_bf16_supported(430, False, 1024, True, 64, 1024, 430)    # k-contiguous operand, K % 8 != 0
     assert ops.gemm_bf16_supported(432, True, 1024, True, 430, 1024, 1024)       # padded pitch covers the tail
+
+
+def test_wgrad_group_equals_single_launches(dev):
+    """Two and three clipped-sum-shaped products in one launch against the per-product launches and f64;
+    products that cannot share a launch are refused without launching anything."""
+    from vqa_amd import ops
+    K = 1024
+    shapes = [(2048, 1024), (1024, 2048), (2048, 1536)]
+    items, singles, wants = [], [], []
+    for i, (M, N) in enumerate(shapes):
+        A, Ah = _operand(20 + i, K, M, M, dev, scale=0.1)
+        B, Bh = _operand(30 + i, K, N, N + 8, dev)
+        C = torch.full((M, N), float("nan"), device=dev)
+        cs = torch.full((M,), float("nan"), device=dev)
+        items.append((A, B, C, cs if i != 1 else None))
+        C1 = torch.empty(M, N, device=dev)
+        cs1 = torch.empty(M, device=dev)
+        ops.gemm_bf16(A, True, B, True, M, N, K, C1, colsum=cs1)
+        singles.append((C1, cs1))
+        wants.append((Ah.t() @ Bh, Ah.sum(0)))
+    for n in (2, 3):
+        for _, _, C, cs in items:
+            C.fill_(float("nan"))
+        assert ops.gemm_bf16_wgrad_group(items[:n], K)
+        for (A, B, C, cs), (C1, cs1), (want, wcs) in list(zip(items, singles, wants))[:n]:
+            assert torch.equal(C, C1)  # same tiles, same order of accumulation
+            np.testing.assert_allclose(C.cpu().numpy(), want.numpy(), rtol=1e-5, atol=3e-6 * float(want.abs().max()))
+            if cs is not None:
+                assert torch.equal(cs, cs1)
+    # accumulate adds a second product
+    assert ops.gemm_bf16_wgrad_group(items[:2], K, accumulate=True)
+    np.testing.assert_allclose(items[0][2].cpu().numpy(), 2 * wants[0][0].numpy(), rtol=1e-5,
+                               atol=6e-6 * float(wants[0][0].abs().max()))
+    # a narrow product (few tiles: wants its contraction split) cannot join
+    A, _ = _operand(41, K, 256, 256, dev)
+    B, _ = _operand(42, K, 128, 128, dev)
+    C = torch.zeros(256, 128, device=dev)
+    assert ops.gemm_bf16_wgrad_group([items[0], (A, B, C, None)], K) is False

@@ -108,6 +108,7 @@ SIGNATURES = {
                                      _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
                                      c_float, c_int, _P]),
     "vqaf_gemm_bf16_supported": (c_int, [c_long, c_int, c_long, c_int, c_int, c_int, c_int]),
+    "vqaf_gemm_bf16_wgrad_group": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, _P, _P]),
     "vqaf_gemm_bf16": (c_int, [_P, c_long, c_int, _P, c_long, c_int, c_int, c_int, c_int, _P, c_int, _P, c_long,
                                c_int, c_int, _P, _P]),
     "vqaf_ghost_sqnorm_linear": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),

@@ -91,7 +91,7 @@ __device__ __forceinline__ int kswz(int k) {
 // fall on 16 distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int rswz(int r) { return (r >> 1) & 7; }
 
-template <int MT, bool A_KMAJOR, bool B_KMAJOR, bool COLSUM>
+template <int MT, bool A_KMAJOR, bool B_KMAJOR, bool COLSUM, int STAGES = GB_STAGES>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile_m, const int tile_n) {
   constexpr int BM = 64 * MT;
   constexpr int A_BYTES = BM * GB_BK * 2;
@@ -168,7 +168,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile
                                          (reinterpret_cast<unsigned long long>(zeros) & ~m));
   };
   auto issue = [&](int t) {
-    unsigned char* st = gb_lds + (t % GB_STAGES) * STAGE_BYTES + wave * 1024;
+    unsigned char* st = gb_lds + (t % STAGES) * STAGE_BYTES + wave * 1024;
     const int kbase = t * GB_BK;
 #pragma unroll
     for (int j = 0; j < NLA; ++j)
@@ -184,15 +184,15 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile
     // this wave are outstanding.  After the barrier every consumer is done with k-step t-1, whose
     // ring slot the next fetch overwrites.
 #pragma unroll
-    for (int s = 0; s < GB_STAGES - 1; ++s)
+    for (int s = 0; s < STAGES - 1; ++s)
       if (s < T) issue(s);
     for (int t = 0; t < T; ++t) {
-      const int younger = min(GB_STAGES - 2, T - 1 - t);
+      const int younger = min(STAGES - 2, T - 1 - t);
       if (younger >= 2) wait_vmcnt<2 * LPS>();
       else if (younger == 1) wait_vmcnt<LPS>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      if (t + GB_STAGES - 1 < T) issue(t + GB_STAGES - 1);
+      if (t + STAGES - 1 < T) issue(t + STAGES - 1);
     }
     return;
   }
@@ -292,7 +292,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile
   for (int t = 0; t < T; ++t) {
     // the loaders waited for their parts of k-step t before this barrier
     __builtin_amdgcn_s_barrier();
-    const unsigned img = lds_base + (unsigned)((t % GB_STAGES) * STAGE_BYTES);
+    const unsigned img = lds_base + (unsigned)((t % STAGES) * STAGE_BYTES);
     // the reads of k16 step ks+1 are in flight while step ks multiplies
     Frags f0, f1;
     load_frags(f0, img, 0);
@@ -347,7 +347,19 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile
   }
 }
 
-template <int MT, bool A_KMAJOR, bool B_KMAJOR>
+__device__ __forceinline__ void tile_of(const GemmArgs& g, const int id, int& tile_m, int& tile_n) {
+  if (g.reg_m > 0) {
+    const int xcd = id & 7, slot = id >> 3;
+    const int bm = g.tiles_m / g.reg_m, bn = g.tiles_n / g.reg_n;
+    tile_m = (xcd / g.reg_n) * bm + slot / bn;
+    tile_n = (xcd % g.reg_n) * bn + slot % bn;
+  } else {
+    tile_m = id / g.tiles_n;
+    tile_n = id % g.tiles_n;
+  }
+}
+
+template <int MT, bool A_KMAJOR, bool B_KMAJOR, int STAGES = GB_STAGES>
 __global__ void __launch_bounds__(2 * GB_THREADS)
 gemm_bf16_kernel(GemmArgs g) {
   // Workgroup -> output tile.  Workgroups are dealt round-robin over the 8 XCDs, each with its own
@@ -355,23 +367,43 @@ gemm_bf16_kernel(GemmArgs g) {
   // regions, each XCD gets one region: its workgroups then share a few operand panels that fit its
   // L2, instead of every XCD streaming all of A (speed only; any mapping is correct).
   int tile_m, tile_n;
-  {
-    const int id = blockIdx.x;
-    if (g.reg_m > 0) {
-      const int xcd = id & 7, slot = id >> 3;
-      const int bm = g.tiles_m / g.reg_m, bn = g.tiles_n / g.reg_n;
-      tile_m = (xcd / g.reg_n) * bm + slot / bn;
-      tile_n = (xcd % g.reg_n) * bn + slot % bn;
-    } else {
-      tile_m = id / g.tiles_n;
-      tile_n = id % g.tiles_n;
-    }
-  }
+  tile_of(g, (int)blockIdx.x, tile_m, tile_n);
   // the column-sum variant of the loop runs only in the workgroups of the first tile column, as a
   // separate instantiation: a runtime condition around its MFMAs would make the compiler shuttle
   // the extra accumulators between register files at every k-step of every workgroup
-  if (g.colsum != nullptr && tile_n == 0) gemm_bf16_body<MT, A_KMAJOR, B_KMAJOR, true>(g, tile_m, tile_n);
-  else gemm_bf16_body<MT, A_KMAJOR, B_KMAJOR, false>(g, tile_m, tile_n);
+  if (g.colsum != nullptr && tile_n == 0) gemm_bf16_body<MT, A_KMAJOR, B_KMAJOR, true, STAGES>(g, tile_m, tile_n);
+  else gemm_bf16_body<MT, A_KMAJOR, B_KMAJOR, false, STAGES>(g, tile_m, tile_n);
+}
+
+// Several weight-gradient-shaped products (both operands k-major, the same contraction length) in ONE
+// launch: the clipped sums of the classifier's Linear layers are a few hundred tiles and sixteen k-steps
+// each, so a launch of their own costs each of them as much as its arithmetic.
+constexpr int GB_MAX_GROUP = 4;
+constexpr int GB_GROUP_STAGES = 3;  // 72 KiB per workgroup: two workgroups (of different products) share a CU
+struct GemmGroup {
+  GemmArgs p[GB_MAX_GROUP];
+  int first[GB_MAX_GROUP + 1];  // first workgroup id of each problem; first[n] = grid size
+  int n;
+};
+
+template <int MT>
+__global__ void __launch_bounds__(2 * GB_THREADS)
+gemm_bf16_wgrad_group_kernel(GemmGroup G) {
+  const int id = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GB_MAX_GROUP; ++i)
+    if (i < G.n && id >= G.first[i]) pi = i;
+  // uniform selects (no indexed access to the by-value argument)
+  GemmArgs g = G.p[0];
+  int base = G.first[0];
+  if (pi == 1) { g = G.p[1]; base = G.first[1]; }
+  if (pi == 2) { g = G.p[2]; base = G.first[2]; }
+  if (pi == 3) { g = G.p[3]; base = G.first[3]; }
+  int tile_m, tile_n;
+  tile_of(g, id - base, tile_m, tile_n);
+  if (g.colsum != nullptr && tile_n == 0) gemm_bf16_body<MT, true, true, true, GB_GROUP_STAGES>(g, tile_m, tile_n);
+  else gemm_bf16_body<MT, true, true, false, GB_GROUP_STAGES>(g, tile_m, tile_n);
 }
 
 constexpr int GB_MAX_DEVICES = 64;
@@ -399,15 +431,15 @@ int zero_block_on_current_device(const unsigned int** out) {
   return VQAF_OK;
 }
 
-template <int MT, bool AK, bool BK_>
+template <int MT, bool AK, bool BK_, int STAGES = GB_STAGES>
 int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
-  constexpr size_t smem = (size_t)GB_STAGES * (64 * MT + GB_BN) * GB_BK * 2;
+  constexpr size_t smem = (size_t)STAGES * (64 * MT + GB_BN) * GB_BK * 2;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<MT, AK, BK_>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<MT, AK, BK_, STAGES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   });
-  hipLaunchKernelGGL((gemm_bf16_kernel<MT, AK, BK_>), grid, dim3(2 * GB_THREADS), smem, st, g);
+  hipLaunchKernelGGL((gemm_bf16_kernel<MT, AK, BK_, STAGES>), grid, dim3(2 * GB_THREADS), smem, st, g);
   return hipGetLastError() == hipSuccess ? VQAF_OK : VQAF_E_LAUNCH;
 }
 
@@ -419,6 +451,89 @@ extern "C" int vqaf_gemm_bf16_supported(long lda, int a_kmajor, long ldb, int b_
   if (a_kmajor ? ((M + 7) / 8 * 8 > lda) : (K % 8 != 0 || K > lda)) return 0;
   if (b_kmajor ? ((N + 7) / 8 * 8 > ldb) : (K % 8 != 0 || K > ldb)) return 0;
   return 1;
+}
+
+namespace {
+// tile plan of one product; false when it would want the contraction split (few tiles)
+bool plan_wgrad(GemmArgs& g, int& MT, int M, int N, int K) {
+  const long tiles128 = (long)((M + 127) / 128) * ((N + GB_BN - 1) / GB_BN);
+  MT = (tiles128 >= 200 || M > 4096) ? 2 : 1;
+  const int BM = 64 * MT;
+  g.tiles_m = (M + BM - 1) / BM;
+  g.tiles_n = (N + GB_BN - 1) / GB_BN;
+  g.reg_m = g.reg_n = 0;
+  const int cand[4][2] = {{2, 4}, {4, 2}, {1, 8}, {8, 1}};
+  long best = -1;
+  for (const auto& c : cand) {
+    if (g.tiles_m % c[0] != 0 || g.tiles_n % c[1] != 0) continue;
+    const long cost = (long)(g.tiles_m / c[0]) * BM + (long)(g.tiles_n / c[1]) * GB_BN;
+    if (best < 0 || cost < best) { best = cost; g.reg_m = c[0]; g.reg_n = c[1]; }
+  }
+  g.M = M; g.N = N; g.K = K;
+  g.k_per_split = (K + GB_BK - 1) / GB_BK * GB_BK;
+  return (long)g.tiles_m * g.tiles_n >= 192;
+}
+}  // namespace
+
+extern "C" int vqaf_gemm_bf16_wgrad_group(int n, const void* const* A, const long* lda, const void* const* B,
+                                          const long* ldb, const int* M, const int* N, int K, float* const* C,
+                                          const long* ldc, int accumulate, float* const* colsum,
+                                          vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(A && lda && B && ldb && M && N && C && ldc, VQAF_E_NULL);
+  VQAF_REQUIRE(n >= 1 && n <= GB_MAX_GROUP && K > 0, VQAF_E_SHAPE);
+  const unsigned int* zeros = nullptr;
+  const int rc = zero_block_on_current_device(&zeros);
+  if (rc != VQAF_OK) return rc;
+  GemmGroup G;
+  G.n = n;
+  int mt_all = 0, next = 0;
+  for (int i = 0; i < n; ++i) {
+    VQAF_REQUIRE(A[i] && B[i] && C[i], VQAF_E_NULL);
+    VQAF_REQUIRE(M[i] > 0 && N[i] > 0 && ldc[i] >= N[i], VQAF_E_SHAPE);
+    VQAF_REQUIRE(vqaf_gemm_bf16_supported(lda[i], 1, ldb[i], 1, M[i], N[i], K), VQAF_E_ALIGN);
+    VQAF_REQUIRE(vqaf_aligned16(A[i]) && vqaf_aligned16(B[i]), VQAF_E_ALIGN);
+    GemmArgs& g = G.p[i];
+    int MT = 1;
+    // a product with too few tiles wants its contraction split, and products of different tile heights
+    // need different kernels: the caller launches those one by one
+    VQAF_REQUIRE(plan_wgrad(g, MT, M[i], N[i], K), VQAF_E_SHAPE);
+    VQAF_REQUIRE(i == 0 || MT == mt_all, VQAF_E_SHAPE);
+    mt_all = MT;
+    g.A = reinterpret_cast<const bf16_t*>(A[i]);
+    g.B = reinterpret_cast<const bf16_t*>(B[i]);
+    g.bias = nullptr;
+    g.bias_bf16 = 0;
+    g.C = C[i];
+    g.colsum = colsum ? colsum[i] : nullptr;
+    g.zeros = zeros;
+    g.lda = lda[i]; g.ldb = ldb[i]; g.ldc = ldc[i];
+    g.out_mode = accumulate ? GB_OUT_F32_ACC : GB_OUT_F32;
+    G.first[i] = next;
+    next += g.tiles_m * g.tiles_n;
+  }
+  for (int i = n; i <= GB_MAX_GROUP; ++i) G.first[i] = next;
+  for (int i = n; i < GB_MAX_GROUP; ++i) G.p[i] = G.p[0];
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)next, 1, 1);
+  if (mt_all == 2) {
+    constexpr size_t smem = (size_t)GB_GROUP_STAGES * (128 + GB_BN) * GB_BK * 2;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_wgrad_group_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    hipLaunchKernelGGL(gemm_bf16_wgrad_group_kernel<2>, grid, dim3(2 * GB_THREADS), smem, st, G);
+  } else {
+    constexpr size_t smem = (size_t)GB_GROUP_STAGES * (64 + GB_BN) * GB_BK * 2;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_wgrad_group_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    hipLaunchKernelGGL(gemm_bf16_wgrad_group_kernel<1>, grid, dim3(2 * GB_THREADS), smem, st, G);
+  }
+  VQAF_LAUNCH_CHECK();
 }
 
 extern "C" int vqaf_gemm_bf16(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor,
@@ -438,7 +553,11 @@ extern "C" int vqaf_gemm_bf16(const void* A, long lda, int a_kmajor, const void*
   hipStream_t st = (hipStream_t)stream;
   // tile height: 128 rows unless that leaves the chip half empty
   const long tiles128 = (long)((M + 127) / 128) * ((N + GB_BN - 1) / GB_BN);
-  const int MT = (tiles128 >= 200 || M > 4096) ? 2 : 1;
+  // A few hundred tiles over a short contraction (the classifier's own GEMMs: sixteen k-steps): a workgroup's
+  // life is mostly pipeline fill and epilogue, so 64 x 64 tiles on a three-deep ring (48 KiB) put three
+  // workgroups on a CU and overlap one's fill with another's arithmetic (measured: 0.428 -> 0.421 ms per step).
+  const bool small3 = tiles128 >= 200 && tiles128 <= 512 && K <= 2048 && M <= 4096;
+  const int MT = small3 ? 1 : ((tiles128 >= 200 || M > 4096) ? 2 : 1);
   const int BM = 64 * MT;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + GB_BN - 1) / GB_BN;
   VQAF_REQUIRE((long)tiles_m * tiles_n < (1l << 30), VQAF_E_SHAPE);
@@ -495,6 +614,11 @@ extern "C" int vqaf_gemm_bf16(const void* A, long lda, int a_kmajor, const void*
     if (!a_kmajor && !b_kmajor) return launch_gemm<MTv, false, false>(g, grid, st);  \
     return launch_gemm<MTv, true, false>(g, grid, st);                               \
   } while (0)
+  if (small3) {
+    if (a_kmajor && b_kmajor) return launch_gemm<1, true, true, 3>(g, grid, st);
+    if (!a_kmajor && b_kmajor) return launch_gemm<1, false, true, 3>(g, grid, st);
+    if (!a_kmajor && !b_kmajor) return launch_gemm<1, false, false, 3>(g, grid, st);
+  }
   if (MT == 2) VQAF_GB(2);
   VQAF_GB(1);
 #undef VQAF_GB

@@ -556,7 +556,21 @@ class DPOptimizer:
             zn = (ctypes.c_size_t * len(zero))(*[z.numel() for z in zero])
             check(lib.vqaf_zero_multi(zp, zn, len(zero), st), "vqaf_zero_multi")
         acc = 1 if pre_zeroed else 0
+        # the wide Linear layers' sums (S = G^T A, column sums of G) share ONE launch when each fills the chip
+        grouped = []
+        if prescaled:
+            cand = [t for t in tapes if t.kind == "linear" and t.g.dtype == torch.bfloat16 and
+                    t.a.dtype == torch.bfloat16 and t.g.is_contiguous() and
+                    ops.gemm_bf16_supported(t.g.shape[1], True, t.a.shape[1], True, t.g.shape[1], t.a.shape[1], B)]
+            if 2 <= len(cand) <= 4:
+                items = [(t.g, t.a, self._slice(S, t.module.weight).view(t.g.shape[1], t.a.shape[1]),
+                          self._slice(S, t.module.bias) if t.module.bias is not None else None) for t in cand]
+                probe = "clipped_sum_linear:" + "+".join(f"{t.g.shape[1]}x{t.a.shape[1]}" for t in cand)
+                if ops.gemm_bf16_wgrad_group(items, B, name=probe):
+                    grouped = cand
         for t in tapes:
+            if any(t is c for c in grouped):
+                continue
             a, g = t.a, t.g.contiguous()
             m = t.module
             if t.kind == "linear":

@@ -759,6 +759,37 @@ def gemm_bf16(A: torch.Tensor, a_kmajor: bool, B: torch.Tensor, b_kmajor: bool, 
     return out
 
 
+@torch.no_grad()
+def gemm_bf16_wgrad_group(items, K: int, accumulate: bool = False, name: Optional[str] = None) -> bool:
+    """items: list of (A (K,M) bf16, B (K,N) bf16, C (M,N) f32 view, colsum (M) f32 or None).  Launches all
+    C_i = A_i^T B_i in one kernel (vqaf_gemm_bf16_wgrad_group); returns False, having launched nothing, when
+    the products cannot share a launch (the caller then issues them one by one)."""
+    import ctypes
+    n = len(items)
+    if not 1 <= n <= 4:
+        return False
+    for A, B, Cm, cs in items:
+        assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and Cm.dtype == torch.float32
+        assert A.stride(1) == 1 and B.stride(1) == 1 and Cm.stride(1) == 1 and A.shape[0] == K and B.shape[0] == K
+    vp, lg, it = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+    has_cs = any(cs is not None for _, _, _, cs in items)
+    if name is not None:
+        _probe(name, "begin")
+    status = load().vqaf_gemm_bf16_wgrad_group(
+        n, vp(*[A.data_ptr() for A, _, _, _ in items]), lg(*[A.stride(0) for A, _, _, _ in items]),
+        vp(*[B.data_ptr() for _, B, _, _ in items]), lg(*[B.stride(0) for _, B, _, _ in items]),
+        it(*[A.shape[1] for A, _, _, _ in items]), it(*[B.shape[1] for _, B, _, _ in items]), K,
+        vp(*[Cm.data_ptr() for _, _, Cm, _ in items]), lg(*[Cm.stride(0) for _, _, Cm, _ in items]), int(accumulate),
+        vp(*[None if cs is None else cs.data_ptr() for _, _, _, cs in items]) if has_cs else None,
+        stream_ptr(items[0][0].device))
+    if name is not None:
+        _probe(name, "end")
+    if status == -1:  # VQAF_E_SHAPE: not groupable
+        return False
+    check(status, "vqaf_gemm_bf16_wgrad_group")
+    return True
+
+
 def keep_count(n_tokens: int, prune_ratio: float) -> int:
     """k = max(1, int(N * (1 - prune_ratio))) in Python double arithmetic (utils/fusion.py:41)."""
     return max(1, int(n_tokens * (1 - prune_ratio)))
