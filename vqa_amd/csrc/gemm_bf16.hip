@@ -456,8 +456,7 @@ extern "C" int vqaf_gemm_bf16_supported(long lda, int a_kmajor, long ldb, int b_
 namespace {
 // tile plan of one product; false when it would want the contraction split (few tiles)
 bool plan_wgrad(GemmArgs& g, int& MT, int M, int N, int K) {
-  const long tiles128 = (long)((M + 127) / 128) * ((N + GB_BN - 1) / GB_BN);
-  MT = (tiles128 >= 200 || M > 4096) ? 2 : 1;
+  MT = (M > 4096 || K > 2048) ? 2 : 1;  // short contractions: 64 x 64 tiles, three workgroups per CU
   const int BM = 64 * MT;
   g.tiles_m = (M + BM - 1) / BM;
   g.tiles_n = (N + GB_BN - 1) / GB_BN;
