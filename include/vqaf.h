@@ -499,12 +499,14 @@ int vqaf_groupnorm_bwd(const void* grad_y, const void* y, const void* xhat, cons
  * Replaces nn.CrossEntropyLoss(reduction='none') (attack/metric_src.py:313-314, 335, 354)
  * and softmax -> max (attack/metric_src.py:376-377, 415).  logits (B,C) `dtype`,
  * targets (B) int64; loss, conf (B) f32 and pred (B) int64 may each be NULL.
- * grad_logits (B,C) f32, if non-NULL, receives grad_scale * (softmax - onehot): the
- * backward of the mean-reduced training loss (utils/src.py:96,99) with grad_scale = 1/B.
+ * grad_logits (B,C) `grad_dtype`, if non-NULL, receives grad_scale * (softmax - onehot): the
+ * backward of the mean-reduced training loss (utils/src.py:96,99) with grad_scale = 1/B; written in
+ * the logits' own dtype it IS the gradient loss.backward() hands to the classifier (incoming
+ * gradient 1), with no further launch.
  * ------------------------------------------------------------------------------------ */
 int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, int C, int dtype,
-                 float* loss, float* conf, int64_t* pred, float* grad_logits, float grad_scale,
-                 vqaf_stream_t stream);
+                 float* loss, float* conf, int64_t* pred, void* grad_logits, int grad_dtype,
+                 float grad_scale, vqaf_stream_t stream);
 
 /* out[i] = in[i] * scale[0] (scale in device memory), written as `out_dtype`: the backward of the
  * mean cross-entropy of utils/src.py:96 -- the logits gradient vqaf_ce_conf produced in the forward

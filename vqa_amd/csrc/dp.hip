@@ -811,11 +811,11 @@ groupnorm_bwd_kernel(const void* __restrict__ grad_y, const void* __restrict__ y
 }
 
 // One wave per row of logits.
-template <bool BF16>
+template <bool BF16, bool GBF16>
 __global__ void __launch_bounds__(DP_THREADS)
 ce_conf_kernel(const void* __restrict__ logits, const int64_t* __restrict__ targets, int B, int C,
                float* __restrict__ loss, float* __restrict__ conf, int64_t* __restrict__ pred,
-               float* __restrict__ grad_logits, float grad_scale) {
+               void* __restrict__ grad_logits, float grad_scale) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (DP_THREADS / 64) + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -844,7 +844,7 @@ ce_conf_kernel(const void* __restrict__ logits, const int64_t* __restrict__ targ
   if (grad_logits != nullptr) {
     for (int c = lane; c < C; c += 64) {
       const float p = expf(load1<BF16>(logits, (size_t)b * C + c) - m) / z;
-      grad_logits[(size_t)b * C + c] = grad_scale * (p - ((int64_t)c == t ? 1.f : 0.f));
+      store1<GBF16>(grad_logits, (size_t)b * C + c, grad_scale * (p - ((int64_t)c == t ? 1.f : 0.f)));
     }
   }
 }
@@ -1162,17 +1162,21 @@ extern "C" int vqaf_groupnorm_bwd(const void* grad_y, const void* y, const void*
 }
 
 extern "C" int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, int C, int dtype,
-                            float* loss, float* conf, int64_t* pred, float* grad_logits,
+                            float* loss, float* conf, int64_t* pred, void* grad_logits, int grad_dtype,
                             float grad_scale, vqaf_stream_t stream) {
   VQAF_ENTRY();
   VQAF_REQUIRE(logits != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE((loss == nullptr && grad_logits == nullptr) || targets != nullptr, VQAF_E_NULL);
-  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype) && (grad_logits == nullptr || vqaf_dtype_ok(grad_dtype)), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && C > 0, VQAF_E_SHAPE);
   const int rows_per_block = DP_THREADS / 64;
-  VQAF_BY_DTYPE(ce_conf_kernel, dim3((B + rows_per_block - 1) / rows_per_block), dim3(DP_THREADS),
-                (hipStream_t)stream, logits, targets, B, C, loss, conf, pred, grad_logits,
-                grad_scale);
+  const dim3 grid((B + rows_per_block - 1) / rows_per_block), block(DP_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+#define VQAF_CE(LB, GB) hipLaunchKernelGGL((ce_conf_kernel<LB, GB>), grid, block, 0, st, logits, targets, B, C, loss, conf, pred, grad_logits, grad_scale)
+  const bool gb = grad_logits != nullptr && grad_dtype == VQAF_BF16;
+  if (dtype == VQAF_BF16) { if (gb) VQAF_CE(true, true); else VQAF_CE(true, false); }
+  else { if (gb) VQAF_CE(false, true); else VQAF_CE(false, false); }
+#undef VQAF_CE
   VQAF_LAUNCH_CHECK();
 }
 

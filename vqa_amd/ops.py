@@ -677,19 +677,21 @@ def pruned_pool(mods, out_dtype: torch.dtype) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 @torch.no_grad()
 def ce_conf(logits: torch.Tensor, targets: Optional[torch.Tensor] = None, want_loss: bool = True,
-            want_conf: bool = True, want_pred: bool = False, grad_scale: Optional[float] = None):
+            want_conf: bool = True, want_pred: bool = False, grad_scale: Optional[float] = None,
+            grad_dtype: torch.dtype = torch.float32):
     """Per-sample cross-entropy, max-softmax confidence, argmax and (optionally) the gradient of
-    grad_scale * sum_i CE_i w.r.t. the logits.  Returns (loss, conf, pred, grad)."""
+    grad_scale * sum_i CE_i w.r.t. the logits (f32, or bf16 on request).  Returns (loss, conf, pred, grad)."""
     B, C = logits.shape
     lg = logits.contiguous()
     dev = lg.device
     loss = torch.empty(B, dtype=torch.float32, device=dev) if (want_loss and targets is not None) else None
     conf = torch.empty(B, dtype=torch.float32, device=dev) if want_conf else None
     pred = torch.empty(B, dtype=torch.int64, device=dev) if want_pred else None
-    grad = torch.empty(B, C, dtype=torch.float32, device=dev) if grad_scale is not None else None
+    grad = torch.empty(B, C, dtype=grad_dtype, device=dev) if grad_scale is not None else None
     tg = targets.to(torch.int64).contiguous() if targets is not None else None
     check(load().vqaf_ce_conf(ptr(lg), ptr(tg), B, C, dtype_code(lg), ptr(loss), ptr(conf), ptr(pred),
-                              ptr(grad), float(grad_scale or 0.0), stream_ptr(dev)), "vqaf_ce_conf")
+                              ptr(grad), dtype_code(grad) if grad is not None else 0, float(grad_scale or 0.0),
+                              stream_ptr(dev)), "vqaf_ce_conf")
     return loss, conf, pred, grad
 
 
@@ -700,7 +702,9 @@ class _MeanCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets):
         B = logits.shape[0]
-        loss, _, _, grad = ce_conf(logits, targets, want_loss=True, want_conf=False, grad_scale=1.0 / B)
+        # the gradient is written in the logits' dtype: with the usual incoming gradient of 1 it is handed on as is
+        gdt = logits.dtype if logits.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        loss, _, _, grad = ce_conf(logits, targets, want_loss=True, want_conf=False, grad_scale=1.0 / B, grad_dtype=gdt)
         ctx.save_for_backward(grad)
         ctx.in_dtype = logits.dtype
         return loss.mean()
@@ -708,14 +712,16 @@ class _MeanCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (grad,) = ctx.saved_tensors
-        # one launch: the product is rounded straight into the logits' dtype
-        if ctx.in_dtype in (torch.float32, torch.bfloat16) and grad_out.numel() == 1:
+        if grad_out is _unit_grads.get((grad_out.device, grad_out.dtype)) and grad.dtype == ctx.in_dtype:
+            return grad, None  # loss.backward(gradient=unit_gradient(loss)): the factor is exactly 1
+        if grad.dtype == torch.float32 and ctx.in_dtype in (torch.float32, torch.bfloat16) and grad_out.numel() == 1:
+            # one launch: the product is rounded straight into the logits' dtype
             out = torch.empty(grad.shape, dtype=ctx.in_dtype, device=grad.device)
             go = grad_out.reshape(1).to(torch.float32)  # a view for the usual f32 scalar
             check(load().vqaf_scale_cast(ptr(grad), ptr(go), grad.numel(), dtype_code(out), ptr(out),
                                          stream_ptr(grad.device)), "vqaf_scale_cast")
             return out, None
-        return (grad * grad_out).to(ctx.in_dtype), None
+        return (grad.float() * grad_out).to(ctx.in_dtype), None
 
 
 def cross_entropy_mean(logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
