@@ -443,6 +443,13 @@ int vqaf_clipped_sum_affine(const void* xhat, const void* g, const float* coef, 
                             int dtype, int accumulate, float* Sgamma, float* Sbeta,
                             vqaf_stream_t stream);
 
+/* The same sums for n <= 8 affine layers in one launch (the GroupNorm layers of the classifier): arrays
+ * of n pointers / widths; coef (B) f32 or NULL is shared; the sums are ACCUMULATED into Sgamma_i /
+ * Sbeta_i (atomics), which the caller zeroes (vqaf_zero_multi). */
+int vqaf_clipped_sum_affine_multi(int n, const void* const* xhat, const void* const* g, const float* coef,
+                                  int B, const int* C, int dtype, float* const* Sgamma,
+                                  float* const* Sbeta, vqaf_stream_t stream);
+
 /* grad[i] = (S[i] + noise_std * z_i) * scale  over n f32 elements
  * (Opacus DPOptimizer.add_noise + scale_grad; noise_std = noise_multiplier * max_grad_norm,
  * scale = 1/expected_batch_size).  z = noise[i] if `noise` is non-NULL, else N(0,1) drawn in

@@ -677,3 +677,34 @@ def test_in_kernel_counter_bumps_and_zero_multi(dev):
         want[lo:hi] = 0
     assert torch.equal(buf.cpu(), want)
     assert lib.vqaf_zero_multi(zp, zn, 9, st) != 0
+
+
+def test_affine_sums_of_several_layers_in_one_launch(dev):
+    """vqaf_clipped_sum_affine_multi against the per-layer entry point (layers of different widths, with and
+    without the clip factors, both storage types)."""
+    import ctypes
+    from vqa_amd._lib import check, dtype_code, load, ptr, stream_ptr
+    lib = load()
+    B = 200
+    for dtype in (torch.float32, torch.bfloat16):
+        widths = [256, 1024, 72]
+        xs = [gi.normal(300 + i, B, C).to(dtype).to(dev) for i, C in enumerate(widths)]
+        gs = [gi.normal(310 + i, B, C).to(dtype).to(dev) for i, C in enumerate(widths)]
+        coef = torch.rand(B, generator=torch.Generator().manual_seed(5)).to(dev)
+        for cf in (coef, None):
+            want = []
+            for x, g, C in zip(xs, gs, widths):
+                sg, sb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+                check(lib.vqaf_clipped_sum_affine(ptr(x), ptr(g), ptr(cf), B, C, dtype_code(g), 1, ptr(sg), ptr(sb),
+                                                  stream_ptr(dev)), "single")
+                want.append((sg, sb))
+            got = [(torch.zeros(C, device=dev), torch.zeros(C, device=dev)) for C in widths]
+            n = len(widths)
+            vp = ctypes.c_void_p * n
+            check(lib.vqaf_clipped_sum_affine_multi(n, vp(*[ptr(x) for x in xs]), vp(*[ptr(g) for g in gs]), ptr(cf), B,
+                                                    (ctypes.c_int * n)(*widths), dtype_code(gs[0]),
+                                                    vp(*[ptr(a) for a, _ in got]), vp(*[ptr(b) for _, b in got]),
+                                                    stream_ptr(dev)), "multi")
+            for (a, b), (wa, wb) in zip(got, want):
+                np.testing.assert_allclose(a.cpu().numpy(), wa.cpu().numpy(), rtol=1e-5, atol=1e-5)
+                np.testing.assert_allclose(b.cpu().numpy(), wb.cpu().numpy(), rtol=1e-5, atol=1e-5)

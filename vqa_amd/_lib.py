@@ -118,6 +118,7 @@ SIGNATURES = {
                                 _P]),
     "vqaf_clipped_sum_linear": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_clipped_sum_affine": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "vqaf_clipped_sum_affine_multi": (c_int, [c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P]),
     "vqaf_noise_scale": (c_int, [_P, _P, _P, c_float, c_float, c_size_t, _P, _P]),
     "vqaf_dp_adamw": (c_int, [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, c_float, c_float,
                               c_float, c_float, c_float, _P, c_int, _P]),

@@ -485,10 +485,9 @@ clipped_sum_linear_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __res
 // last bits of these sums may differ from run to run.)
 constexpr int AF_ROWS = 64;
 template <bool BF16>
-__global__ void __launch_bounds__(DP_THREADS)
-clipped_sum_affine_kernel(const void* __restrict__ xhat, const void* __restrict__ g,
-                          const float* __restrict__ coef, int B, int C,
-                          float* __restrict__ Sgamma, float* __restrict__ Sbeta) {
+__device__ __forceinline__ void clipped_sum_affine_body(const void* __restrict__ xhat, const void* __restrict__ g,
+                                                        const float* __restrict__ coef, int B, int C,
+                                                        float* __restrict__ Sgamma, float* __restrict__ Sbeta) {
   __shared__ float r0[16][128], r1[16][128];
   const int tid = threadIdx.x, r16 = tid >> 4, cc = (tid & 15) * 8;
   const int c0 = blockIdx.x * 128 + cc;
@@ -530,6 +529,38 @@ clipped_sum_affine_kernel(const void* __restrict__ xhat, const void* __restrict_
     if (Sgamma != nullptr) atomicAdd(Sgamma + c, vg);
     if (Sbeta != nullptr) atomicAdd(Sbeta + c, vb);
   }
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(DP_THREADS)
+clipped_sum_affine_kernel(const void* __restrict__ xhat, const void* __restrict__ g,
+                          const float* __restrict__ coef, int B, int C,
+                          float* __restrict__ Sgamma, float* __restrict__ Sbeta) {
+  clipped_sum_affine_body<BF16>(xhat, g, coef, B, C, Sgamma, Sbeta);
+}
+
+// The same sums for up to AF_MAX affine layers in one launch (blockIdx.z picks the layer).
+constexpr int AF_MAX = 8;
+struct AffineLayers {
+  const void* xhat[AF_MAX];
+  const void* g[AF_MAX];
+  float* Sgamma[AF_MAX];
+  float* Sbeta[AF_MAX];
+  int C[AF_MAX];
+};
+template <bool BF16>
+__global__ void __launch_bounds__(DP_THREADS)
+clipped_sum_affine_multi_kernel(AffineLayers L, const float* __restrict__ coef, int B) {
+  const void* xhat = nullptr;
+  const void* g = nullptr;
+  float* sg = nullptr;
+  float* sb = nullptr;
+  int C = 0;
+#pragma unroll
+  for (int i = 0; i < AF_MAX; ++i)
+    if (i == (int)blockIdx.z) { xhat = L.xhat[i]; g = L.g[i]; sg = L.Sgamma[i]; sb = L.Sbeta[i]; C = L.C[i]; }
+  if ((int)blockIdx.x * 128 >= C) return;  // the grid is as wide as the widest layer (uniform per workgroup)
+  clipped_sum_affine_body<BF16>(xhat, g, coef, B, C, sg, sb);
 }
 
 // grad[i] = (S[i] + std * z_i) * scale; z_{4c..4c+3} = draw c of stream (seed, counter).
@@ -1038,6 +1069,28 @@ extern "C" int vqaf_clipped_sum_affine(const void* xhat, const void* g, const fl
   VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);
   VQAF_BY_DTYPE(clipped_sum_affine_kernel, grid, dim3(DP_THREADS), st, xhat, g, coef, B, C, Sgamma,
                 Sbeta);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_clipped_sum_affine_multi(int n, const void* const* xhat, const void* const* g,
+                                             const float* coef, int B, const int* C, int dtype,
+                                             float* const* Sgamma, float* const* Sbeta, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(xhat && g && C && Sgamma && Sbeta, VQAF_E_NULL);
+  VQAF_REQUIRE(n >= 1 && n <= AF_MAX && B > 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  AffineLayers L = {};
+  int widest = 0;
+  for (int i = 0; i < n; ++i) {
+    VQAF_REQUIRE(xhat[i] && g[i], VQAF_E_NULL);
+    VQAF_REQUIRE(C[i] > 0, VQAF_E_SHAPE);
+    VQAF_REQUIRE(C[i] % 8 == 0 && vqaf_aligned16(xhat[i]) && vqaf_aligned16(g[i]), VQAF_E_ALIGN);
+    L.xhat[i] = xhat[i]; L.g[i] = g[i]; L.Sgamma[i] = Sgamma[i]; L.Sbeta[i] = Sbeta[i]; L.C[i] = C[i];
+    widest = C[i] > widest ? C[i] : widest;
+  }
+  const dim3 grid((widest + 127) / 128, (B + AF_ROWS - 1) / AF_ROWS, n);
+  VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);
+  VQAF_BY_DTYPE(clipped_sum_affine_multi_kernel, grid, dim3(DP_THREADS), (hipStream_t)stream, L, coef, B);
   VQAF_LAUNCH_CHECK();
 }
 

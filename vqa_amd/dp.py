@@ -568,6 +568,19 @@ class DPOptimizer:
                 probe = "clipped_sum_linear:" + "+".join(f"{t.g.shape[1]}x{t.a.shape[1]}" for t in cand)
                 if ops.gemm_bf16_wgrad_group(items, B, name=probe):
                     grouped = cand
+        # the affine (GroupNorm) layers' sums share one launch too when their slices are already zeroed
+        affine = [t for t in tapes if t.kind != "linear"]
+        if pre_zeroed and 2 <= len(affine) <= 8 and all(t.g.dtype == affine[0].g.dtype and t.g.is_contiguous()
+                                                         and t.a.is_contiguous() for t in affine):
+            import ctypes
+            n = len(affine)
+            vp = ctypes.c_void_p * n
+            check(lib.vqaf_clipped_sum_affine_multi(
+                n, vp(*[ptr(t.a) for t in affine]), vp(*[ptr(t.g) for t in affine]), None if prescaled else ptr(coef),
+                B, (ctypes.c_int * n)(*[t.g.shape[1] for t in affine]), dtype_code(affine[0].g),
+                vp(*[ptr(self._slice(S, t.module.weight)) for t in affine]),
+                vp(*[ptr(self._slice(S, t.module.bias)) for t in affine]), st), "vqaf_clipped_sum_affine_multi")
+            grouped = grouped + affine
         for t in tapes:
             if any(t is c for c in grouped):
                 continue
