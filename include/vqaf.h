@@ -316,6 +316,21 @@ typedef struct vqaf_fused_mod {
 int vqaf_fused_prune_pool_multi(const vqaf_fused_mod* mods_host, int n_mod, int B, int D, int H, int dtype,
                                 uint64_t* sel_rng_state, int rng_advance, void* out, int ld_out,
                                 int out_dtype, vqaf_stream_t stream);
+/* The same call on a ONE-PASS kernel (utils/fusion.py:234-254, 274, as above): a sample's rows are read
+ * from memory once and stay in registers / LDS of the compute unit between scoring and pooling (a wave
+ * keeps three 16-token tiles as raw bf16 in registers, a thirteenth tile lives in LDS), and the pooled
+ * sums are formed on the matrix cores (tiles pass through a small LDS image and come back through the
+ * transposing LDS read as the operand of weights x tokens; every product is exact).  Identical keep
+ * indices, random streams and output layout; the pooled features agree with the two-pass kernel's to
+ * f32 summation order.  It halves the kernel's traffic over the memory fabric; at 256 registers per
+ * lane only two workgroups fit a compute unit, and on MI355X its launch takes about as long as the
+ * two-pass one, which is why vqaf_fused_prune_pool_multi stays on the two-pass kernel and this one is
+ * asked for by name.  Limits: D == 512, every N <= 208, H <= 8 (vqaf_fused_prune_pool_onepass_supported:
+ * 1 / 0); other shapes return VQAF_E_SHAPE. */
+int vqaf_fused_prune_pool_onepass_supported(int n_mod, const int* N, int D, int H);
+int vqaf_fused_prune_pool_onepass_multi(const vqaf_fused_mod* mods_host, int n_mod, int B, int D, int H,
+                                        int dtype, uint64_t* sel_rng_state, int rng_advance, void* out,
+                                        int ld_out, int out_dtype, vqaf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense single-query cross-attention (non-pruning branch): the attention OUTPUT of

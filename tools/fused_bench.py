@@ -12,6 +12,7 @@ B, D, H = int(os.environ.get("B", 1024)), 512, 8
 NV, NQ = int(os.environ.get("NV", 197)), 30
 nbuf = 4
 NOISE = os.environ.get("NOISE")  # gaussian | uniform | unset
+ops.FUSED_ONE_PASS = os.environ.get("ONEPASS") is not None  # ONEPASS=1: the one-pass kernel
 gen = torch.Generator(device=dev).manual_seed(1)
 vs = [torch.randn(B, NV, D, device=dev, generator=gen).bfloat16() for _ in range(nbuf)]
 qs = [torch.randn(B, NQ, D, device=dev, generator=gen).bfloat16() for _ in range(nbuf)]

@@ -101,6 +101,9 @@ SIGNATURES = {
     "vqaf_prune_mix": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_uint64, _P, c_int,
                                c_float, _P, c_int, c_float, c_int, _P, _P, _P]),
     "vqaf_fused_prune_pool_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P]),
+    "vqaf_fused_prune_pool_onepass_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int,
+                                                    c_int, _P]),
+    "vqaf_fused_prune_pool_onepass_supported": (c_int, [c_int, _P, c_int, c_int]),
     "vqaf_gemm_f32": (c_int, [_P, c_int, c_long, c_long, c_long, _P, c_int, c_long, c_long, c_long,
                               _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
                               c_float, c_int, _P]),

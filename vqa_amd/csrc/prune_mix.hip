@@ -53,7 +53,7 @@ struct PmCarve {
 __host__ __device__ inline PmCarve pm_carve(int N, int K, int NP, int k_adv) {
   PmCarve c;
   size_t o = 0;
-  c.keys = o;  o += pm_align16((size_t)NP * 8);
+  c.keys = o;  o += pm_align16((size_t)(NP + 2) * 8);
   c.rank = o;  o += pm_align16((size_t)N * 4);
   c.s_pos = o; o += pm_align16((size_t)(k_adv > 0 ? 2 * k_adv : 1) * 4);
   c.wl = o;    o += pm_align16((size_t)N * 4);

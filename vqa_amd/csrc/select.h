@@ -173,16 +173,46 @@ __device__ inline void bitonic_sort_desc(unsigned long long* keys, int NP) {
 // for rows of up to 256 weights (measured: N = 30: 4.0 vs 5.2 us, N = 197: 7.3 vs 8.3 us per
 // launch); its N^2 work loses beyond that (N = 577: 24 vs 14 us), where the network is kept.
 constexpr int RANK_COUNT_MAX_N = 256;
-__device__ __forceinline__ int count_greater(const unsigned long long* keys, int NP, unsigned long long ki) {
+// `keys` is 16-byte aligned; M keys are compared (no padding is read).
+__device__ __forceinline__ int count_greater(const unsigned long long* keys, int M, unsigned long long ki) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   int rank = 0;
+  const int even = M & ~1;
 #pragma unroll 8
-  for (int j = 0; j < NP; j += 2) {
+  for (int j = 0; j < even; j += 2) {
     const u64x2 kk = *reinterpret_cast<const u64x2*>(keys + j);
     rank += (kk.x > ki) ? 1 : 0;
     rank += (kk.y > ki) ? 1 : 0;
   }
+  if (M & 1) rank += (keys[even] > ki) ? 1 : 0;
   return rank;
+}
+
+// Wave-wide reductions whose result reaches every lane with the same bits: exchanges between
+// lanes 1, 2, 4, 8 apart by DPP, between rows of 16 lanes and wave halves by the swap
+// instructions; the order of the additions depends on the lane distance only.
+__device__ __forceinline__ float sel_readlane(float v, int l) {
+  return __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+}
+__device__ __forceinline__ float sel_wave_allmax(float v) {
+  v = fmaxf(v, __uint_as_float(sel_lane_xor32<1>(__float_as_uint(v))));
+  v = fmaxf(v, __uint_as_float(sel_lane_xor32<2>(__float_as_uint(v))));
+  v = fmaxf(v, __uint_as_float(sel_lane_xor32<4>(__float_as_uint(v))));
+  v = fmaxf(v, __uint_as_float(sel_lane_xor32<8>(__float_as_uint(v))));
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+__device__ __forceinline__ float sel_wave_allsum(float v) {
+  v += __uint_as_float(sel_lane_xor32<1>(__float_as_uint(v)));
+  v += __uint_as_float(sel_lane_xor32<2>(__float_as_uint(v)));
+  v += __uint_as_float(sel_lane_xor32<4>(__float_as_uint(v)));
+  v += __uint_as_float(sel_lane_xor32<8>(__float_as_uint(v)));
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);  // (even row) + (odd row) on both lanes
+  const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(c[0]) + __uint_as_float(c[1]);
 }
 
 // Random k_adv-prefix of a uniform permutation of [0,M): rank M random 51-bit keys (ties are
@@ -226,11 +256,48 @@ __device__ inline void random_prefix_positions(unsigned long long* keys, int M, 
   }
   __syncthreads();
   for (int i = tid; i < M; i += nt) {
-    const int r = count_greater(keys, NP, keys[i]);
+    const int r = count_greater(keys, M, keys[i]);
     if (r < take) out[r] = i;
   }
   __syncthreads();
 }
+
+__device__ __forceinline__ unsigned long long random_prefix_key(unsigned long long seed, unsigned long long counter,
+                                                                unsigned long long stream_id, int i) {
+  const Philox4 r = philox4x32_10(seed, stream_id * (unsigned long long)TK_MAX_N + i, counter);
+  const unsigned long long r51 = (((unsigned long long)r.x << 32) | r.y) >> 13;
+  return (1ull << 63) | (r51 << 12) | (unsigned long long)(TK_MAX_N - 1 - i);
+}
+
+// The same reductions over HH independent values at once (instruction-level parallelism: with few
+// waves per SIMD a single dependent chain of cross-lane steps is all latency).  Per value the
+// operations and their order are exactly those of sel_wave_allmax / sel_wave_allsum.
+template <int HH, bool IS_MAX>
+__device__ __forceinline__ void sel_wave_allreduce_n(float (&v)[HH]) {
+  auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; };
+#pragma unroll
+  for (int h = 0; h < HH; ++h) v[h] = op(v[h], __uint_as_float(sel_lane_xor32<1>(__float_as_uint(v[h]))));
+#pragma unroll
+  for (int h = 0; h < HH; ++h) v[h] = op(v[h], __uint_as_float(sel_lane_xor32<2>(__float_as_uint(v[h]))));
+#pragma unroll
+  for (int h = 0; h < HH; ++h) v[h] = op(v[h], __uint_as_float(sel_lane_xor32<4>(__float_as_uint(v[h]))));
+#pragma unroll
+  for (int h = 0; h < HH; ++h) v[h] = op(v[h], __uint_as_float(sel_lane_xor32<8>(__float_as_uint(v[h]))));
+#pragma unroll
+  for (int h = 0; h < HH; ++h) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[h]), __float_as_uint(v[h]), false, false);
+    v[h] = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  }
+#pragma unroll
+  for (int h = 0; h < HH; ++h) {
+    const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[h]), __float_as_uint(v[h]), false, false);
+    v[h] = op(__uint_as_float(c[0]), __uint_as_float(c[1]));
+  }
+}
+
+#ifndef SEL_STAMP
+#define SEL_STAMP(i) do {} while (0)
+#endif
 
 // LDS arrays of one sample's selection.
 struct SelectLds {
@@ -242,36 +309,148 @@ struct SelectLds {
   float* stat;               // [2*SEL_MAX_H]
 };
 
+// The two adversarial draws of one sample (adv_mode 2): a random k_adv-prefix of a permutation of the
+// K keep-list positions -> L.s_pos[0..k_adv), and of the R bottom-list positions ->
+// L.s_pos[k_adv..2*k_adv).  They depend on (seed, counter, stream_b) and the list lengths only, not
+// on the weights, so a kernel may call this before its scores exist (while its rows are still in
+// flight) and pass draws_done = true to select_core.  Uses L.keys (NP + 2 entries) as scratch.
+// When both lists are short enough for the counting rank, one half of the workgroup draws the
+// positions while the other draws the sources.  All threads call it; ends with a barrier.
+__device__ inline void select_draws(const SelectLds& L, int K, int R, int NPK, int NPR, int k_adv,
+                                    unsigned long long seed, unsigned long long counter,
+                                    unsigned long long stream_b) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  int* s_src = L.s_pos + k_adv;
+  if (K <= RANK_COUNT_MAX_N && R <= RANK_COUNT_MAX_N && (nt & 127) == 0) {
+    const int hn = nt >> 1;
+    const int which = tid >= hn ? 1 : 0, t = tid - which * hn;
+    const int M = which ? R : K;
+    unsigned long long* keys = L.keys + (which ? ((K + 1) & ~1) : 0);
+    int* out = which ? s_src : L.s_pos;
+    const unsigned long long sid = 2ull * stream_b + (unsigned long long)which;
+    for (int i = t; i < M; i += hn) keys[i] = random_prefix_key(seed, counter, sid, i);
+    __syncthreads();
+    for (int i = t; i < M; i += hn) {
+      const int r = count_greater(keys, M, keys[i]);
+      if (r < k_adv) out[r] = i;
+    }
+    __syncthreads();
+  } else {
+    random_prefix_positions(L.keys, K, NPK, seed, counter, 2ull * stream_b, k_adv, L.s_pos);
+    random_prefix_positions(L.keys, R, NPR, seed, counter, 2ull * stream_b + 1ull, k_adv, s_src);
+  }
+}
+
 // Whole keep-index selection of one sample by one workgroup, on LDS arrays:
 //   (H > 0) softmax per head over sl -> head mean -> wl;   keys -> ranking -> rank[];
 //   bottom list reported (before the swap, as the reference keeps it);
 //   adversarial swap with injected (adv_mode 1) or in-kernel (adv_mode 2) draws.
 // On entry sl (H > 0) or wl (H == 0) is filled and visible to the workgroup; on return rank[0..K)
 // is the keep list and all threads have passed a barrier.  pos_b / src_b / the *_out_b pointers are
-// this sample's rows (already offset by the sample index).
+// this sample's rows (already offset by the sample index).  draws_done: select_draws has run.
+//
+// The softmax statistics are formed per chunk of 64 tokens (one wave-wide reduction each) and the
+// chunks are then combined in index order, so the weights do not depend on the workgroup's size.
 __device__ inline void select_core(const SelectLds& L, int H, int N, int K, int NP, int adv_mode, int k_adv,
                                    int NPK, int NPR, const int64_t* pos_b, const int64_t* src_b,
                                    unsigned long long seed, unsigned long long counter, unsigned long long stream_b,
-                                   float* w_out_b, int64_t* bottom_b, int64_t* pos_out_b, int64_t* src_out_b) {
+                                   float* w_out_b, int64_t* bottom_b, int64_t* pos_out_b, int64_t* src_out_b,
+                                   bool draws_done = false) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   const int R = N - K;
-  if (H > 0) {
-    for (int h = wave; h < H; h += nw) {  // a wave owns a head: no workgroup barrier inside
-      float m = -INFINITY;
-      for (int n = lane; n < N; n += 64) m = fmaxf(m, L.sl[n * H + h]);
-      m = wave_max(m);
-      float z = 0.f;
-      for (int n = lane; n < N; n += 64) z += expf(L.sl[n * H + h] - m);
-      z = wave_sum(z);
-      if (lane == 0) { L.stat[h] = m; L.stat[SEL_MAX_H + h] = z; }
+  if (H == 8 && ((N + 63) >> 6) <= nw && (reinterpret_cast<size_t>(L.sl) & 15) == 0) {
+    // Eight heads, at most one chunk per wave: thread n owns token n, its eight scores stay in
+    // registers, the eight reductions run side by side.  Same arithmetic, value for value, as the
+    // general form below.
+    constexpr int HH = 8;
+    const int nchunks = (N + 63) >> 6;
+    float* cm = reinterpret_cast<float*>(L.keys);
+    float* cz = cm + nchunks * HH;
+    const bool mine = wave < nchunks, real = tid < N;
+    float v[HH], e[HH];
+    if (mine) {
+      if (real) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(L.sl + tid * HH), c = *reinterpret_cast<const f32x4*>(L.sl + tid * HH + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+      } else {
+#pragma unroll
+        for (int h = 0; h < HH; ++h) v[h] = -INFINITY;
+      }
+      float mx[HH];
+#pragma unroll
+      for (int h = 0; h < HH; ++h) mx[h] = v[h];
+      sel_wave_allreduce_n<HH, true>(mx);
+      float pick = mx[0];
+#pragma unroll
+      for (int h = 1; h < HH; ++h) pick = lane == h ? mx[h] : pick;
+      if (lane < HH) cm[wave * HH + lane] = pick;
     }
     __syncthreads();
+    float mv = -INFINITY;
+    if (lane < HH)
+      for (int c = 0; c < nchunks; ++c) mv = fmaxf(mv, cm[c * HH + lane]);
+    if (mine) {
+      float zs[HH];
+#pragma unroll
+      for (int h = 0; h < HH; ++h) {
+        e[h] = real ? expf(v[h] - sel_readlane(mv, h)) : 0.f;
+        zs[h] = e[h];
+      }
+      sel_wave_allreduce_n<HH, false>(zs);
+      float pick = zs[0];
+#pragma unroll
+      for (int h = 1; h < HH; ++h) pick = lane == h ? zs[h] : pick;
+      if (lane < HH) cz[wave * HH + lane] = pick;
+    }
+    SEL_STAMP(0);
+    __syncthreads();
+    float zv = 0.f;
+    if (lane < HH)
+      for (int c = 0; c < nchunks; ++c) zv += cz[c * HH + lane];
+    if (mine && real) {
+      float a = 0.f;
+#pragma unroll
+      for (int h = 0; h < HH; ++h) a += e[h] / sel_readlane(zv, h);
+      L.wl[tid] = a / (float)HH;
+    }
+    SEL_STAMP(1);
+    __syncthreads();
+  } else if (H > 0) {
+    const int nchunks = (N + 63) >> 6;
+    float* cm = reinterpret_cast<float*>(L.keys);  // [nchunks][H] chunk maxima (the keys come later)
+    float* cz = cm + nchunks * H;                  // [nchunks][H] chunk sums
+    for (int c = wave; c < nchunks; c += nw) {
+      const int n = 64 * c + lane;
+      for (int h = 0; h < H; ++h) {
+        const float v = sel_wave_allmax(n < N ? L.sl[n * H + h] : -INFINITY);
+        if (lane == h) cm[c * H + h] = v;
+      }
+    }
+    __syncthreads();
+    float mv = -INFINITY;  // lane h: maximum of head h
+    if (lane < H)
+      for (int c = 0; c < nchunks; ++c) mv = fmaxf(mv, cm[c * H + lane]);
+    for (int c = wave; c < nchunks; c += nw) {
+      const int n = 64 * c + lane;
+      for (int h = 0; h < H; ++h) {
+        const float m = sel_readlane(mv, h);
+        const float z = sel_wave_allsum(n < N ? expf(L.sl[n * H + h] - m) : 0.f);
+        if (lane == h) cz[c * H + h] = z;
+      }
+    }
+    SEL_STAMP(0);
+    __syncthreads();
+    float zv = 0.f;  // lane h: sum of head h, chunks added in index order
+    if (lane < H)
+      for (int c = 0; c < nchunks; ++c) zv += cz[c * H + lane];
     for (int n = tid; n < N; n += nt) {
       float a = 0.f;
-      for (int h = 0; h < H; ++h) a += expf(L.sl[n * H + h] - L.stat[h]) / L.stat[SEL_MAX_H + h];
+      for (int h = 0; h < H; ++h)
+        a += expf(L.sl[n * H + h] - sel_readlane(mv, h)) / sel_readlane(zv, h);
       L.wl[n] = a / (float)H;
     }
+    SEL_STAMP(1);
     __syncthreads();
   }
   if (w_out_b != nullptr)
@@ -281,12 +460,14 @@ __device__ inline void select_core(const SelectLds& L, int H, int N, int K, int 
                            (unsigned long long)(0xffffffffu - (unsigned int)i))
                         : 0ull;
   __syncthreads();
+  SEL_STAMP(2);
   if (N <= RANK_COUNT_MAX_N) {
-    for (int i = tid; i < N; i += nt) L.rank[count_greater(L.keys, NP, L.keys[i])] = i;
+    for (int i = tid; i < N; i += nt) L.rank[count_greater(L.keys, N, L.keys[i])] = i;
   } else {
     bitonic_sort_desc(L.keys, NP);
     for (int r = tid; r < N; r += nt) L.rank[r] = (int)(0xffffffffu - (unsigned int)L.keys[r]);
   }
+  SEL_STAMP(3);
   __syncthreads();
   if (bottom_b != nullptr)
     for (int i = tid; i < R; i += nt) bottom_b[i] = (int64_t)L.rank[N - 1 - i];
@@ -299,8 +480,8 @@ __device__ inline void select_core(const SelectLds& L, int H, int N, int K, int 
     __syncthreads();
   } else if (adv_mode == 2) {
     int* s_src = L.s_pos + k_adv;
-    random_prefix_positions(L.keys, K, NPK, seed, counter, 2ull * stream_b, k_adv, L.s_pos);
-    random_prefix_positions(L.keys, R, NPR, seed, counter, 2ull * stream_b + 1ull, k_adv, s_src);
+    if (!draws_done) select_draws(L, K, R, NPK, NPR, k_adv, seed, counter, stream_b);
+    SEL_STAMP(5);
     for (int j = tid; j < k_adv; j += nt) {
       const int p = L.s_pos[j];
       const int q = s_src[j];

@@ -23,7 +23,7 @@ __global__ void topk_kernel(const float* __restrict__ w, int N, int K, int NP,
   const int R = N - K;
   if (N <= RANK_COUNT_MAX_N) {
     for (int i = tid; i < N; i += nt) {
-      const int r = count_greater(keys, NP, keys[i]);
+      const int r = count_greater(keys, N, keys[i]);
       if (r < K) top[(size_t)b * K + r] = (int64_t)i;
       else if (bottom != nullptr) bottom[(size_t)b * R + (N - 1 - r)] = (int64_t)i;
     }
@@ -93,11 +93,11 @@ __global__ void select_kernel(SelectMods mods, int H, const uint64_t* __restrict
   const SelectMod& M_ = mods.m[blockIdx.y];
   const float* __restrict__ s = M_.s;
   const int N = M_.N, K = M_.K, NP = M_.NP, k_adv = M_.k_adv;
-  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [NP]
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];  // [NP + 2]
   __shared__ float stat[2 * SEL_MAX_H];
   SelectLds L;
-  L.keys = keys;
-  L.sl = reinterpret_cast<float*>(keys + NP);                           // [N*H] head scores (16-B aligned)
+  L.keys = keys;                                                        // [NP + 2]
+  L.sl = reinterpret_cast<float*>(keys + NP + 2);                       // [N*H] head scores (16-B aligned)
   const int slots = (s != nullptr) ? ((N * H + 3) & ~3) : 0;
   L.rank = reinterpret_cast<int*>(L.sl + slots);                        // [N] full ranking
   L.s_pos = L.rank + N;                                                 // [2*k_adv]: positions, sources
@@ -204,7 +204,7 @@ static int select_fill(SelectMod& m, const float* s, const float* w_in, int N, i
   const int NP = next_pow2(N);
   m = SelectMod{s, w_in, pos, src, w_out, top, bottom, pos_out, src_out, (unsigned long long)salt,
                 N, K, NP, adv_mode, k_adv, next_pow2(K), next_pow2(R > 0 ? R : 1)};
-  const size_t need = (size_t)NP * 8 + (size_t)N * 4 + (size_t)(k_adv > 0 ? 2 * k_adv : 1) * 4 + (size_t)N * 4 +
+  const size_t need = (size_t)(NP + 2) * 8 + (size_t)N * 4 + (size_t)(k_adv > 0 ? 2 * k_adv : 1) * 4 + (size_t)N * 4 +
                       (s != nullptr ? (size_t)((N * H + 3) & ~3) * 4 : 0);
   VQAF_REQUIRE(need <= 64 * 1024, VQAF_E_SHAPE);
   *smem = need > *smem ? need : *smem;

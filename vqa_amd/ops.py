@@ -53,6 +53,7 @@ def default_rng(device: torch.device) -> PhiloxState:
 
 
 IN_KERNEL_RNG_BUMP = False  # let vqaf_fused_prune_pool_multi advance its generator state itself
+FUSED_ONE_PASS = False  # True: the one-launch pruning branch takes the one-pass kernel where it applies (D = 512, N <= 208)
 
 # Optional measurement probe: bench.py installs a callable (name, phase) -> None that records
 # stream events around a named kernel launch; None in normal use.
@@ -587,8 +588,13 @@ class _FusedPrunePool(torch.autograd.Function):
         check(lib.vqaf_fold_query_multi(ctypes.cast(folds, ctypes.c_void_p), n_mod, B, D, H, dtype_code(seq0),
                                         _lib.BF16 if w_dt == torch.bfloat16 else _lib.F32, st), "vqaf_fold_query_multi")
         _probe("fused_prune_pool", "begin")
-        check(lib.vqaf_fused_prune_pool_multi(ctypes.cast(fm, ctypes.c_void_p), n_mod, B, D, H, dtype_code(seq0),
-                                              ptr(rng_state), int(rng_advance), ptr(out), ld, dtype_code(out), st),
+        entry = lib.vqaf_fused_prune_pool_multi
+        if FUSED_ONE_PASS:
+            ns = (ctypes.c_int * n_mod)(*[m[0].shape[1] for m in mods])
+            if lib.vqaf_fused_prune_pool_onepass_supported(n_mod, ctypes.cast(ns, ctypes.c_void_p), D, H):
+                entry = lib.vqaf_fused_prune_pool_onepass_multi
+        check(entry(ctypes.cast(fm, ctypes.c_void_p), n_mod, B, D, H, dtype_code(seq0),
+                    ptr(rng_state), int(rng_advance), ptr(out), ld, dtype_code(out), st),
               "vqaf_fused_prune_pool_multi")
         _probe("fused_prune_pool", "end")
         if not rng_advance:  # the kernel did not bump the counter itself: one launch per noise stream
