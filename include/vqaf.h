@@ -271,8 +271,10 @@ int vqaf_gather_mix_pool_bwd_multi(const void* grad_out, int ld_out, int g_dtype
  * in flight.  w (B,N) f32 attention weights; out (B, K + (alpha > 0), D); idx_out (B,K) int64 keep
  * indices.  Same results as vqaf_select + vqaf_gather_mix: same ranking, same draws for the same
  * rng states (noise_counter_offset as in vqaf_fused_mod), kept rows bit-exact copies.
- * vqaf_prune_mix_supported: N <= 592 for bf16 tokens, N <= 208 for f32 tokens (a lane keeps its
- * rows in registers); other sizes return VQAF_E_SHAPE and callers use the two entry points. */
+ * vqaf_prune_mix_supported (1 / 0): D % 8 == 0, a sample below 2 GiB, and the per-sample selection
+ * state within 64 KiB of LDS for EVERY K <= N and k_adv <= N / 2 (8 * nextpow2(N) + 20 * N + about
+ * 16.5 KiB: N up to 1630), so a supported size never turns into a shape error at the launch; other
+ * sizes return VQAF_E_SHAPE and callers use the two entry points (vqaf_select + vqaf_gather_mix). */
 int vqaf_prune_mix_supported(int N, int D, int dtype);
 int vqaf_prune_mix(const void* seq, const float* w, int B, int N, int K, int D, int dtype, int adv_mode,
                    int k_adv, const int64_t* pos, const int64_t* src, const uint64_t* sel_rng_state,

@@ -152,3 +152,86 @@ def test_two_rank_poisson_shards_are_disjoint(tmp_path):
     # sums of ~100 clipped per-sample gradients in f32, grouped differently on the two sides
     np.testing.assert_allclose(got["total"].numpy(), want.numpy(), rtol=1e-5,
                                atol=1e-5 * float(want.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Non-private gradients: batch-weighted mean over the ranks (vqa_amd.dist.GradReducer), the exchange
+# in front of optimizer['main'].step() (reference: train.py:156-160, utils/src.py:103)
+# ---------------------------------------------------------------------------------------------------
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.enc = torch.nn.Linear(IN, HID)
+        self.idle = torch.nn.Linear(IN, 3)  # never used in forward: its gradient is None on every rank
+        self.head = torch.nn.Linear(HID, C)
+
+    def forward(self, x):
+        return self.head(torch.tanh(self.enc(x)))
+
+
+def _net():
+    torch.manual_seed(77)
+    return _Net()
+
+
+def _reducer_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    vdist.init_from_env(backend="gloo")
+    net = _net()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    red = vdist.GradReducer(net.parameters())
+    x, y = gi.normal(1, B, IN), gi.labels(2, B, C)
+    # step 1: unequal shards (5 and 7 samples); step 2: rank 1 has an EMPTY batch
+    shards = [((0, 5), (5, 12)), ((0, 12), None)]
+    grads = []
+    for step in shards:
+        opt.zero_grad()
+        part = step[rank]
+        if part is None:
+            red.reduce(0)
+        else:
+            lo, hi = part
+            torch.nn.functional.cross_entropy(net(x[lo:hi]), y[lo:hi]).backward()
+            red.reduce(hi - lo)
+        assert net.idle.weight.grad is None
+        grads.append(torch.cat([p.grad.reshape(-1) for p in (net.enc.weight, net.enc.bias, net.head.weight, net.head.bias)]))
+        opt.step()
+    params = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    torch.save({"grads": grads, "params": params}, os.path.join(out_dir, f"red{rank}.pt"))
+    vdist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_grad_reducer_keeps_replicas_identical(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_reducer_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "red0.pt"), weights_only=True)
+    r1 = torch.load(os.path.join(str(tmp_path), "red1.pt"), weights_only=True)
+    # every rank leaves a step with the same gradient and the same parameters, bit for bit
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(a, b)
+    assert torch.equal(r0["params"], r1["params"])
+    # ... and they are those of ONE process on the joint batch (mean loss over all 12 samples)
+    net = _net()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    x, y = gi.normal(1, B, IN), gi.labels(2, B, C)
+    for g in r0["grads"]:
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(net(x), y).backward()
+        want = torch.cat([p.grad.reshape(-1) for p in (net.enc.weight, net.enc.bias, net.head.weight, net.head.bias)])
+        np.testing.assert_allclose(g.numpy(), want.numpy(), rtol=2e-5, atol=1e-7)
+        opt.step()
+    np.testing.assert_allclose(r0["params"].numpy(), torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy(),
+                               rtol=2e-5, atol=1e-7)
+
+
+def test_grad_reducer_is_a_no_op_without_a_process_group():
+    net = _net()
+    red = vdist.GradReducer(net.parameters())
+    torch.nn.functional.cross_entropy(net(gi.normal(1, 4, IN)), gi.labels(2, 4, C)).backward()
+    before = net.enc.weight.grad.clone()
+    red.reduce(4)
+    assert torch.equal(net.enc.weight.grad, before)

@@ -70,8 +70,7 @@ def _graph_step(dev, x, y, expected):
     with torch.cuda.graph(g_apply, pool=g_local.pool(), capture_error_mode="thread_local"):
         opt.apply_step()
     g_local.replay()
-    # two processes time-share this one GPU: drain the launch stream before the collective
-    torch.cuda.current_stream().synchronize()
+    # (two processes time-share this one GPU: reduce_step itself drains the launch stream first)
     opt.reduce_step()
     g_apply.replay()
     torch.cuda.synchronize()
@@ -121,3 +120,97 @@ def test_two_ranks_share_one_gpu_over_gloo(tmp_path):
     assert float((r0["graphed"] - r0["quiet"]).abs().max()) < 2e-4
     # noise on: the parameters moved away from the noise-free ones by a noise-sized amount
     assert float((r0["noisy"] - r0["quiet"]).abs().max()) > 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------
+# Whole training step in a process group: loops.train with the {'main', 'classifier'} optimizers of
+# train.py:156-162 -- non-private gradients averaged over the ranks (GradReducer), clipped sums of the
+# classifier all-reduced (DPOptimizer) -- keeps encoder AND classifier replicas identical and equals
+# one process on the joint batch.
+# ---------------------------------------------------------------------------------------------------
+class TinyV(nn.Module):
+    def __init__(self, out_features=512):
+        super().__init__()
+        self.output_dim = out_features
+        self.proj = nn.Linear(48, out_features)
+
+    def forward(self, images):
+        seq = self.proj(images.reshape(images.shape[0], 16, 48))
+        return seq, seq.mean(1)
+
+
+class TinyT(nn.Module):
+    def __init__(self, hidden_dim=512):
+        super().__init__()
+        self.output_dim = hidden_dim
+        self.emb = nn.Embedding(100, hidden_dim)
+
+    def forward(self, ids, mask):
+        seq = self.emb(ids)
+        return seq, seq.mean(1)
+
+
+NS = 24
+
+
+def _samples():
+    g = torch.Generator().manual_seed(9)
+    return (torch.randn(NS, 3, 16, 16, generator=g), torch.randint(0, 100, (NS, 12), generator=g),
+            torch.randint(0, 13, (NS,), generator=g))
+
+
+def _batch_of(lo, hi):
+    img, ids, ans = _samples()
+    return {"image": img[lo:hi], "inputs": {"input_ids": ids[lo:hi], "attention_mask": torch.ones(hi - lo, 12, dtype=torch.long)},
+            "answer": ans[lo:hi]}
+
+
+def _train_steps(dev, batches):
+    from vqa_amd import dp, loops
+    from vqa_amd.model import VQAModel
+    torch.manual_seed(42)
+    model = VQAModel(vision=TinyV, text=TinyT, fusion_type="co_attention", hidden_dim=64, num_classes=13,
+                     use_token_pruning=True, adversarial_mix=False, noise_injection=False)
+    model.classifier = dp.ModuleValidator.fix(model.classifier)
+    model.classifier[3].p = 0.0  # dropout masks depend on a sample's position in its batch
+    model = model.to(dev)
+    gsm = dp.GradSampleModule(model.classifier)
+    model.classifier = gsm
+    cls_opt = dp.DPOptimizer(torch.optim.SGD(gsm.parameters(), lr=0.05), gsm, noise_multiplier=0.0, max_grad_norm=1.0,
+                             expected_batch_size=NS, seed=3)
+    main_params = [p for n, p in model.named_parameters() if not n.startswith('classifier.') and p.requires_grad]
+    optimizer = {'main': torch.optim.SGD(main_params, lr=0.05), 'classifier': cls_opt}
+    loops.train(model, batches, optimizer, nn.CrossEntropyLoss(), dev, use_dp_sgd=True)
+    torch.cuda.synchronize()
+    enc = torch.cat([p.detach().reshape(-1) for n, p in model.named_parameters() if not n.startswith('classifier.')]).cpu()
+    cls = torch.cat([p.detach().reshape(-1) for p in gsm.parameters()]).cpu()
+    return enc, cls
+
+
+def _train_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), VQAF_DIST_BACKEND="gloo", VQAF_SINGLE_DEVICE="1")
+    from vqa_amd import dist as vdist
+    _, local, _ = vdist.init_from_env()
+    dev = vdist.local_device(local)
+    torch.cuda.set_device(dev)
+    assert vdist.ranks_share_device(dev)
+    # step 1: unequal disjoint shards; step 2: rank 1 draws an empty batch
+    batches = [[_batch_of(0, 10), _batch_of(0, NS)], [_batch_of(10, NS), None]][rank]
+    enc, cls = _train_steps(dev, batches)
+    torch.save({"enc": enc, "cls": cls}, os.path.join(out_dir, f"t{rank}.pt"))
+    vdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_training_step_keeps_every_replica_identical(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_train_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "t0.pt"), weights_only=True)
+    r1 = torch.load(os.path.join(str(tmp_path), "t1.pt"), weights_only=True)
+    assert torch.equal(r0["enc"], r1["enc"])   # encoders + fusion: the non-private optimizer
+    assert torch.equal(r0["cls"], r1["cls"])   # classifier: the DP optimizer
+    enc, cls = _train_steps(torch.device("cuda:0"), [_batch_of(0, NS), _batch_of(0, NS)])
+    np.testing.assert_allclose(r0["enc"].numpy(), enc.numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(r0["cls"].numpy(), cls.numpy(), rtol=1e-4, atol=2e-6)

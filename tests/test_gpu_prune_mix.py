@@ -232,3 +232,23 @@ def test_full_size_properties(dev, keep):
     # the mix token is rounded to bf16 once: relative 2^-9 of a sum of (N-k) unit normals
     tol = 2.0 ** -8 * (N - k) ** 0.5 * 4 + 1e-2
     assert float((total - recon).abs().max()) < tol
+
+
+@pytest.mark.parametrize("N,keep,one_launch", [(1600, 0.95, True), (2048, 0.9, False), (4096, 0.5, False)])
+def test_long_sequences_take_whichever_path_holds_their_state(dev, N, keep, one_launch):
+    """vqaf_prune_mix_supported answers for the worst K / k_adv of a length, so the module never meets a
+    shape refusal: long rows go through the one launch while their selection state fits LDS, through
+    select + gather_mix beyond, with the same results either way."""
+    from vqa_amd import fusion, ops
+    assert ops.prune_mix_supported(N, 64, torch.bfloat16) == one_launch
+    mod = fusion.PrivacyAwareTokenPruning(1.0 - keep, 0.05, True, 0.2, False, 0.0, "gaussian")
+    seq = gi.normal(N, 2, N, 64).bfloat16().to(dev)
+    w = _weights(N + 1, 2, N).to(dev)
+    mod.rng = ops.PhiloxState(dev, seed=5)
+    out = mod(seq, w.unsqueeze(1))
+    k = fo.keep_count(N, 1.0 - keep)
+    k_adv = fo.adv_count(k, 0.2) if N - k >= fo.adv_count(k, 0.2) else 0
+    assert out.shape == (2, k + 1, 64)
+    two = _two_launch(seq, w, k, 0.05, k_adv, None, None, None, None, 0.0, 5)
+    assert torch.equal(mod.last_indices, two[1])
+    assert torch.equal(out[:, :k], two[0][:, :k])

@@ -267,7 +267,10 @@ extern "C" int vqaf_prune_mix_supported(int N, int D, int dtype) {
   if (N <= 0 || D <= 0 || D % 8 != 0 || N > TK_MAX_N) return 0;
   if (dtype != VQAF_BF16 && dtype != VQAF_F32) return 0;
   // buffer offsets are 32-bit and the out-of-range marker is 2^31: a sample stays below that
-  return (unsigned long long)N * (unsigned long long)D * 4ull < 0x80000000ull;
+  if ((unsigned long long)N * (unsigned long long)D * 4ull >= 0x80000000ull) return 0;
+  // the per-sample state must fit 64 KiB of LDS whatever K and k_adv the caller then asks for
+  // (K <= N, k_adv <= N / 2), so that "supported" never turns into a shape error at the launch
+  return pm_carve(N, N, sel_next_pow2(N), N / 2).total <= 64 * 1024;
 }
 
 extern "C" int vqaf_prune_mix(const void* seq, const float* w, int B, int N, int K, int D, int dtype,

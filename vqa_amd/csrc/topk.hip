@@ -206,7 +206,7 @@ static int select_fill(SelectMod& m, const float* s, const float* w_in, int N, i
                 N, K, NP, adv_mode, k_adv, next_pow2(K), next_pow2(R > 0 ? R : 1)};
   const size_t need = (size_t)(NP + 2) * 8 + (size_t)N * 4 + (size_t)(k_adv > 0 ? 2 * k_adv : 1) * 4 + (size_t)N * 4 +
                       (s != nullptr ? (size_t)((N * H + 3) & ~3) * 4 : 0);
-  VQAF_REQUIRE(need <= 64 * 1024, VQAF_E_SHAPE);
+  VQAF_REQUIRE(need <= 160 * 1024, VQAF_E_SHAPE);  // one workgroup may take the whole LDS of a compute unit
   *smem = need > *smem ? need : *smem;
   int t = sort_threads(NP);
   if (t < 256) t = 256;  // the score / weight passes want more lanes than the sort
@@ -226,6 +226,9 @@ extern "C" int vqaf_select(const float* s, const float* w_in, int B, int N, int 
   const int rc = select_fill(mods.m[0], s, w_in, N, H, K, adv_mode, k_adv, pos, src, rng_state, salt, w_out, top,
                              bottom, pos_out, src_out, &smem, &threads);
   if (rc != VQAF_OK) return rc;
+  if (smem > 64 * 1024)  // beyond the default limit of dynamic LDS: raise it for this kernel (cheap when already set)
+    VQAF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, VQAF_E_LAUNCH);
   hipLaunchKernelGGL(select_kernel, dim3(B, 1), dim3(threads), smem, (hipStream_t)stream, mods, H, rng_state);
   VQAF_LAUNCH_CHECK();
 }
@@ -244,6 +247,9 @@ extern "C" int vqaf_select_multi(const vqaf_select_desc* descs_host, int n, int 
                                d.salt, d.w_out, d.top, d.bottom, d.pos_out, d.src_out, &smem, &threads);
     if (rc != VQAF_OK) return rc;
   }
+  if (smem > 64 * 1024)  // beyond the default limit of dynamic LDS: raise it for this kernel (cheap when already set)
+    VQAF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, VQAF_E_LAUNCH);
   hipLaunchKernelGGL(select_kernel, dim3(B, n), dim3(threads), smem, (hipStream_t)stream, mods, H, rng_state);
   VQAF_LAUNCH_CHECK();
 }

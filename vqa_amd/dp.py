@@ -651,6 +651,9 @@ class DPOptimizer:
         import torch.distributed as dist
         world, _ = self._world()
         if world > 1:
+            # (ranks that time-share one GPU -- the one-GPU rehearsal -- drain their launch stream first)
+            from .dist import drain_if_device_is_shared
+            drain_if_device_is_shared(self._grad.device, self.process_group)
             dist.all_reduce(self._grad, op=dist.ReduceOp.SUM, group=self.process_group)
 
     @torch.no_grad()

@@ -14,6 +14,7 @@ from typing import Dict, Tuple
 import torch
 import torch.nn as nn
 
+from . import dist as vdist
 from . import ops
 
 
@@ -23,20 +24,44 @@ def _batch(batch, device):
             batch['answer'].to(device))
 
 
+def _main_reducer(optimizer) -> "vdist.GradReducer | None":
+    """The gradient exchange of a NON-private optimizer in a process group (cached on the optimizer);
+    None with one rank, and for a DP optimizer, which reduces its own clipped sums."""
+    if hasattr(optimizer, "reduce_step"):
+        return None
+    red = getattr(optimizer, "_vqaf_reducer", None)
+    if red is None:
+        red = vdist.GradReducer([p for g in optimizer.param_groups for p in g["params"]])
+        optimizer._vqaf_reducer = red
+    return red if red.world() > 1 else None
+
+
 def train(model: nn.Module, train_loader, optimizer, criterion, device, model_type: str = "VQAModel",
           use_dp_sgd: bool = False, lambda_ib: float = 0.01) -> Tuple[float, float]:
-    """One epoch; returns (average loss, accuracy in %) like utils/src.py:123-126."""
+    """One epoch; returns (average loss, accuracy in %) like utils/src.py:123-126.
+
+    In a process group (one rank per GPU, rank-disjoint batches) every replica ends a step with the
+    same parameters: the non-private optimizer steps on the batch-weighted mean of all ranks'
+    gradients (vqa_amd.dist.GradReducer), the DP optimizer on the all-reduced clipped sums."""
     if model_type == "VQAModel_IB":
         raise NotImplementedError("VQAModel_IB is outside the accelerated path")
     model.train()
     split = isinstance(optimizer, dict)
+    main_opt = optimizer['main'] if split else optimizer
+    reducer = _main_reducer(main_opt)
     tot_loss = torch.zeros((), dtype=torch.float64, device=device)
     tot_correct = torch.zeros((), dtype=torch.int64, device=device)
     n = 0
     for batch in train_loader:
         if batch is None:  # an empty Poisson-sampled batch
-            # Opacus still takes (and accounts for) the noise-only step; in a process group the
-            # other ranks are waiting in the all-reduce
+            # the other ranks are waiting in the collectives, in this order: non-private gradients,
+            # then the classifier's clipped sums.  This rank contributes zeros to the first and takes
+            # the same averaged step as everyone else; Opacus still takes (and accounts for) the
+            # noise-only step of the private part.
+            if reducer is not None:
+                main_opt.zero_grad()
+                reducer.reduce(0)
+                main_opt.step()
             if split and hasattr(optimizer['classifier'], 'empty_step'):
                 optimizer['classifier'].empty_step(device)
             elif hasattr(optimizer, 'empty_step'):
@@ -51,12 +76,14 @@ def train(model: nn.Module, train_loader, optimizer, criterion, device, model_ty
         outputs = model(images=images, input_ids=ids, attention_mask=mask)   # :91-95
         loss = criterion(outputs, answers)                                   # :96
         loss.backward(gradient=ops.unit_gradient(loss))                      # :99 (the same unit gradient, cached)
+        b = images.size(0)
+        if reducer is not None:   # replicas: the mean over the ranks' joint batch, as one process would see it
+            reducer.reduce(b)
         if split:                                                            # :102-106
             optimizer['main'].step()
             optimizer['classifier'].step()
         else:
             optimizer.step()
-        b = images.size(0)
         tot_loss += loss.detach().double() * b                              # :109 without .item()
         tot_correct += (outputs.detach().argmax(dim=1) == answers).sum()    # :110
         n += b
