@@ -141,43 +141,22 @@ def build_job(dev, local_b, dtype, rank, logical_b=LOGICAL_BATCH):
     return fus, gsm, opt, main_opt, sets
 
 
-def make_step(fus, gsm, opt, main_opt, sets):
-    """The training step in the order of utils/src.py:66-106, split at the one collective:
-    `local(i)` = zero_grad, forward, loss, backward, main step, per-rank DP work;
-    `reduce()` = the gradient all-reduce (RCCL; nothing at N = 1); `apply()` = the DP update."""
-    from vqa_amd import ops
+def make_step(fus, gsm, opt, main_opt, sets, eager):
+    """The training step in the order of utils/src.py:66-106 as vqa_amd.loops.GraphedStep runs it for
+    any caller of the drop-in modules: zero_grad, forward, mean CE, backward, optimizer['main'] step,
+    per-rank DP work, (RCCL all-reduces outside the graphs when there are several ranks), DP update.
+    The rotating input sets stay where they are (`resident_inputs`): one graph per set, nothing copied."""
+    from vqa_amd import loops, ops
+    gstep = loops.GraphedStep(lambda v, vg, q, qg: gsm(fus(v, vg, q, qg)), {'main': main_opt, 'classifier': opt},
+                              ops.cross_entropy_mean, resident_inputs=True, warmup=(1 << 30) if eager else 2)
 
-    def local(i):
+    def step(i, force_eager=False):
         v, vg, q, qg, y = sets[i % len(sets)]
-        v.grad = None
-        q.grad = None
-        main_opt.zero_grad()
-        opt.zero_grad()
-        fused = fus(v, vg, q, qg)
-        logits = gsm(fused)
-        loss = ops.cross_entropy_mean(logits, y)
-        loss.backward(gradient=ops.unit_gradient(loss))
-        main_opt.step()
-        opt.local_step()
-        return loss
+        if force_eager:
+            return gstep.eager_step((v, vg, q, qg), y)
+        return gstep((v, vg, q, qg), y)
 
-    # Ranks that share one device (the two-rank rehearsal on a one-GPU box) drain the launch
-    # stream before the collective: once a process has replayed a HIP graph, a side stream parked
-    # on an event of the launch stream is never released while two processes time-share the GPU
-    # (measured; with one process per GPU the same hand-off completes).
-    shared_device = os.environ.get("VQAF_SINGLE_DEVICE") == "1"
-
-    def reduce():
-        if shared_device:
-            torch.cuda.current_stream().synchronize()
-        opt.reduce_step()
-
-    def step(i):
-        local(i)
-        reduce()
-        opt.apply_step()
-
-    step.local, step.reduce, step.apply = local, reduce, opt.apply_step
+    step.graphed = gstep
     return step
 
 
@@ -480,84 +459,36 @@ def run_job(args, dev, dtype, rank, world, local_b, logical_b, probe):
     Returns (seconds for the timed steps (max over ranks), launch mode, eager ms/step or None)."""
     from vqa_amd import dist as vdist
     fus, gsm, opt, main_opt, sets = build_job(dev, local_b, dtype, rank, logical_b)
-    step = make_step(fus, gsm, opt, main_opt, sets)
-    # eager warm-up: creates every lazily built buffer (flat gradient bucket, RNG states, RCCL
-    # communicators) before anything is captured
-    for i in range(max(args.warmup, len(sets))):
+    step = make_step(fus, gsm, opt, main_opt, sets, args.eager)
+    # Warm-up: the first two visits of an input set run eagerly (they create every lazily built buffer:
+    # flat gradient bucket, RNG states, RCCL communicators), the third captures that set's HIP graph(s);
+    # replays draw fresh noise because the RNG counters live in device memory.  With several ranks the
+    # collectives stay OUT of the graphs (GraphedStep): graph(local work) -> eager all-reduce ->
+    # graph(update), and the ranks agree on whether capture succeeded.
+    for i in range(max(args.warmup, (4 if not args.eager else 1) * len(sets))):
         step(i)
-    torch.cuda.synchronize()
-    graphs = g_apply = None
-    if not args.eager:
-        # the launch-bound step (about 40 short kernels) is captured once per input set into a HIP
-        # graph; replays draw fresh noise because the RNG counters live in device memory.
-        # With several ranks the collective stays OUT of the graphs: one graph per input set for
-        # the work before it, one for the update after it, and a plain RCCL all-reduce between.
-        ok = 1
-        try:
-            graphs, pool = [], None
-            # thread-local capture mode: the process group's watchdog thread may query events
-            # while this thread captures
-            mode = "thread_local" if world > 1 else "global"
-            for i in range(len(sets)):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
-                    if world == 1:
-                        step(i)
-                    else:
-                        step.local(i)
-                pool = g.pool()
-                graphs.append(g)
-            if world > 1:
-                g_apply = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_apply, pool=pool, capture_error_mode=mode):
-                    step.apply()
-        except Exception as exc:  # capture is an optimisation of the launch path only
-            print(f"[bench] rank {rank}: HIP graph capture unavailable ({type(exc).__name__}: {exc}); "
-                  "timing eager launches", file=sys.stderr)
-            ok = 0
-            torch.cuda.synchronize()
-        if world > 1:
-            # every rank must take the same path: a rank that fell back to eager launches while the
-            # others replay graphs would still match their collectives one for one, but agreeing
-            # first keeps the run uniform and the reported launch mode true for all ranks
-            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-            ok = int(flag.item())
-        if not ok:
-            graphs = g_apply = None
-
-    def run(i):
-        if graphs is None:
-            step(i)
-        else:
-            graphs[i % len(graphs)].replay()
-            if g_apply is not None:
-                step.reduce()
-                g_apply.replay()
-
-    for i in range(max(args.warmup, len(sets) if graphs is not None else 0)):
-        run(i)
     vdist.barrier()
     torch.cuda.synchronize()
+    graphed = step.graphed.launch == "hipgraph"
     if probe is not None:
-        probe.enabled = graphs is None
+        probe.enabled = not graphed
     t0 = time.perf_counter()
     for i in range(args.steps):
-        run(args.warmup + i)
+        step(args.warmup + i)
     torch.cuda.synchronize()
     vdist.barrier()
     dt = time.perf_counter() - t0
     eager_ms = None
     if probe is not None:
         probe.enabled = False
-        if graphs is not None:
+        if graphed:
             # event records are refused inside a captured graph on ROCm, so the probed kernels
             # are timed over the same number of eagerly launched steps right afterwards
             probe.enabled = True
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(args.steps):
-                step(args.warmup + i)
+                step(args.warmup + i, force_eager=True)
             torch.cuda.synchronize()
             eager_ms = (time.perf_counter() - t1) / args.steps * 1e3
             probe.enabled = False
@@ -565,7 +496,7 @@ def run_job(args, dev, dtype, rank, world, local_b, logical_b, probe):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, ("hipgraph" if graphs is not None else "eager"), eager_ms
+    return dt, ("hipgraph" if graphed else "eager"), eager_ms
 
 
 def roofline_obj(probe, local_b, dtype, launch, copy_gbs):

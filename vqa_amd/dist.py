@@ -132,8 +132,8 @@ class GradReducer:
         """Forget which parameters take part (call on every rank after changing what the model trains)."""
         self._live, self._buckets, self._count = None, [], None
 
-    def _setup(self, device: torch.device) -> None:
-        mask = torch.tensor([0 if p.grad is None else 1 for p in self.params], dtype=torch.int32, device=device)
+    def _setup(self, device: torch.device, grads) -> None:
+        mask = torch.tensor([0 if g is None else 1 for g in grads], dtype=torch.int32, device=device)
         dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
         self._live = [i for i, m in enumerate(mask.cpu().tolist()) if m]
         by_dtype: Dict[torch.dtype, List[int]] = {}
@@ -151,22 +151,29 @@ class GradReducer:
         self._count = torch.zeros(1, dtype=torch.float32, device=device)
 
     @torch.no_grad()
-    def reduce(self, local_batch: int) -> None:
+    def reduce(self, local_batch: int, grads: Optional[List[Optional[torch.Tensor]]] = None) -> None:
+        """`grads` (one entry per parameter of this reducer, None where there is none) names the tensors
+        that hold this step's gradients when they are not `param.grad` -- a replayed HIP graph writes
+        them where its capture allocated them, while `param.grad` still shows the previous step's view."""
         if self.world() == 1 or not self.params:
             return
         device = self.params[0].device
+        if grads is None:
+            grads = [p.grad for p in self.params]
         if self._live is None:
-            self._setup(device)
+            self._setup(device, grads)
+        if not self._live:
+            return  # nothing trains through this optimizer (known to every rank alike)
         live = set(self._live)
-        for i, p in enumerate(self.params):
-            if p.grad is not None and i not in live:
+        for i, g in enumerate(grads):
+            if g is not None and i not in live:
                 raise RuntimeError("GradReducer: a parameter received a gradient that had none on any rank when the "
                                    "buckets were laid out; call reset() on every rank after changing what is trained")
         self._count.fill_(float(local_batch))
         for flat, views, idx in self._buckets:
             dst, src = [], []
             for v, i in zip(views, idx):
-                g = self.params[i].grad
+                g = grads[i]
                 if g is None:
                     v.zero_()
                 elif g.data_ptr() != v.data_ptr():

@@ -184,6 +184,20 @@ class _GhostGroupNorm(torch.autograd.Function):
         return gx, None, None, None, None, None, None, None, None, None
 
 
+class _ScaleGrad(torch.autograd.Function):
+    """Identity whose backward multiplies the gradient by a 0-d device tensor (read on the device)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.save_for_backward(scale)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        return g * scale.to(g.dtype), None
+
+
 class GradSampleModule(nn.Module):
     """Wraps the classifier; the wrapped module is `_module`, so state_dict keys gain the
     `_module.` prefix the reference's loader strips (utils/util.py:117-123)."""
@@ -203,10 +217,18 @@ class GradSampleModule(nn.Module):
         self.dropout_rng = None  # seed (and fallback counter) of the fused dropout masks (made on first use)
         self.step_counter = None  # {unused, steps} device words of the attached DP optimizer's fused update
         self._drop_calls = 0      # dropout call sites since the last optimizer step
+        # Optional 0-d device tensor: the gradient that leaves this module towards the non-private part of
+        # the model is multiplied by it.  A step over a zero-padded batch divides the loss by the PADDED
+        # row count (the host-side factor that restores per-sample gradients is fixed in a captured graph);
+        # this factor, padded / real rows, turns the upstream gradients back into those of the mean over
+        # the real rows.  The per-sample gradients of this module are not touched by it.
+        self.input_grad_scale = None
 
     def forward(self, x):
         self.tapes = []
         self.last_batch_size = x.shape[0]
+        if self.input_grad_scale is not None and x.requires_grad:
+            x = _ScaleGrad.apply(x, self.input_grad_scale)
         return self._run(self._module, x)
 
     def _run(self, m: nn.Module, x):
@@ -668,6 +690,9 @@ class DPOptimizer:
             self.accountant_hook(self)
         for t in self.module.tapes:  # a second step() without a new backward must fail loudly
             t.g = None
+        # dropout call sites are numbered within a step (the number salts the mask seed, a host value): a
+        # step replayed from a HIP graph then draws from the same streams as the eagerly launched one
+        self.module._drop_calls = 0
         return result
 
     @torch.no_grad()
