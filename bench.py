@@ -204,6 +204,75 @@ def prune_mix_sweep(dev, dtype):
     return out
 
 
+def one_pass_leg(dev):
+    """The one-launch pruning branch at the step's shape (B = 1024, 197 + 30 tokens, bf16) on its two
+    kernels, timed alone over rotating inputs: the two-pass kernel the step uses and the one-pass kernel
+    (rows read once, held in registers / LDS, pooled on the matrix cores).  Bytes: one-pass algorithmic
+    bytes N*D*s + H*D*4 + K*8 + D*s per sample and modality; fabric traffic from profiles/r03_pmc_fused.json."""
+    from vqa_amd import ops
+    B, H = LOGICAL_BATCH, 8
+    gen = torch.Generator(device=dev).manual_seed(1)
+    vs = [torch.randn(B, N_VIS, D, device=dev, generator=gen).bfloat16() for _ in range(4)]
+    qs = [torch.randn(B, N_TXT, D, device=dev, generator=gen).bfloat16() for _ in range(4)]
+    w = torch.randn(3 * D, D, device=dev, generator=gen) / D ** 0.5
+    bias = torch.randn(3 * D, device=dev, generator=gen) * 0.1
+    qg = torch.randn(B, D, device=dev, generator=gen).bfloat16()
+    rng = ops.PhiloxState(dev, seed=3)
+
+    def specs(i):
+        out = []
+        for seq, n in ((vs[i % 4], N_VIS), (qs[i % 4], N_TXT)):
+            k = ops.keep_count(n, 1 - KEEP)
+            out.append(dict(q=qg, seq=seq, in_proj_weight=w, in_proj_bias=bias, num_heads=H, k=k,
+                            k_adv=ops.adv_count(k, 0.2), alpha=0.05))
+        return out
+
+    class P:
+        def __init__(self):
+            self.t, self.o = [], None
+
+        def __call__(self, name, phase):
+            if name != "fused_prune_pool":
+                return
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            if phase == "begin":
+                self.o = e
+            else:
+                self.t.append((self.o, e))
+
+    K, Kt = ops.keep_count(N_VIS, 1 - KEEP), ops.keep_count(N_TXT, 1 - KEEP)
+    per = lambda n, k: n * D * 2 + H * D * 4 + k * 8 + D * 2  # noqa: E731
+    one_pass_bytes = B * (per(N_VIS, K) + per(N_TXT, Kt))
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_fused.json")) as fh:
+            pmc = json.load(fh)["kernels"]
+    except (OSError, ValueError, KeyError):
+        pmc = {}
+    out, saved_probe, saved_mode = {}, ops.PROBE, ops.FUSED_ONE_PASS
+    try:
+        for label, one, key in (("two_pass", False, "fused_prune_pool_kernel (both)"),
+                                ("one_pass", True, "fused_onepass_kernel (both)")):
+            ops.FUSED_ONE_PASS = one
+            p = P()
+            ops.PROBE = p
+            with torch.no_grad():
+                for i in range(24):
+                    ops.fused_prune_pool(specs(i), torch.bfloat16, rng)
+            torch.cuda.synchronize()
+            ts = sorted(a.elapsed_time(b) for a, b in p.t[4:])
+            ms = ts[len(ts) // 2]
+            traffic = pmc.get(key, {}).get("fabric_bytes_per_launch")
+            out[label] = {"ms": round(ms, 5), "one_pass_GB/s": round(one_pass_bytes / ms / 1e6, 1),
+                          "frac_of_8TBs_on_one_pass_bytes": round(one_pass_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                          "fabric_bytes_per_launch": traffic,
+                          "fabric_over_one_pass_bytes": round(traffic / one_pass_bytes, 3) if traffic else None}
+    finally:
+        ops.PROBE, ops.FUSED_ONE_PASS = saved_probe, saved_mode
+    out["one_pass_bytes"] = one_pass_bytes
+    return out
+
+
 def dense_leg(dev, dtype):
     """The unpruned branch (dense single-query cross-attention, utils/fusion.py:257-268), forward and
     backward with token gradients, at configs[1]'s batch (64 x 197 tokens) and configs[3]'s
@@ -520,7 +589,7 @@ def roofline_obj(probe, local_b, dtype, launch, copy_gbs):
         per = lambda n, k, passes: passes * n * D * s + H * D * 4 + k * 8 + D * s  # noqa: E731
         alg_bytes = local_b * (per(N_VIS, K, 2) + per(N_TXT, Kt, 2))
         one_pass = local_b * (per(N_VIS, K, 1) + per(N_TXT, Kt, 1))
-        pmc_file, pmc_key = "r02_pmc_fused.json", "fused_prune_pool_kernel<16> (both)"
+        pmc_file, pmc_key = "r03_pmc_fused.json", "fused_prune_pool_kernel (both)"
         pmc_field = "fabric_bytes_per_launch"
     else:
         # separate launches (f32 tokens, unsupported widths): the pooled prune+mix launch, every
@@ -532,19 +601,27 @@ def roofline_obj(probe, local_b, dtype, launch, copy_gbs):
         pmc_file, pmc_key = "r01_pmc_traffic.json", "gather_mix_pool_multi_kernel<true, true, 32>"
         pmc_field = "hbm_bytes_per_launch"
     achieved = alg_bytes / k_ms / 1e6 if k_ms > 0 else 0.0
-    try:  # fabric-side bytes per launch from the PMC passes kept under profiles/ (same shape only)
+    # Fabric-side bytes per launch come from counter passes kept under profiles/ (rocprofv3 --pmc cannot
+    # run inside this process); they describe ONE shape, so any other shape reports null and says why.
+    # tools/pmc_fused.sh <tag> regenerates the file for the default shape.
+    traffic_note = None
+    try:
         with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
             pmc = json.load(fh)
-        if local_b == 1024 and dtype == torch.bfloat16:
+        if local_b == 1024 and dtype == torch.bfloat16 and fused:
             traffic = pmc["kernels"][pmc_key][pmc_field]
-    except (OSError, KeyError, ValueError):
-        traffic = None
+            traffic_note = f"profiles/{pmc_file} (FETCH_SIZE x 2 + WRITE_SIZE, separate counter passes, same shape)"
+        else:
+            traffic_note = (f"null: profiles/{pmc_file} holds counters for batch 1024 bf16 only; this run is batch "
+                            f"{local_b} {'bf16' if dtype == torch.bfloat16 else 'f32'}")
+    except (OSError, KeyError, ValueError) as exc:
+        traffic, traffic_note = None, f"null: {type(exc).__name__} reading profiles/{pmc_file}"
     timing = ("stream events around the launch in eagerly launched steps right after the timed region "
               "(the timed region replays HIP graphs)") if launch == "hipgraph" else \
              "stream events around the launch inside the timed region"
     return {"bound": "hbm", "kernel": kname,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
             "kernel_ms": round(k_ms, 5), "algorithmic_bytes": alg_bytes,
             "one_pass_bytes": one_pass,
             "one_pass_GBs": round(one_pass / k_ms / 1e6, 1) if k_ms > 0 else 0.0,
@@ -639,6 +716,8 @@ def main():
         if not args.no_sweep:
             line["prune_mix_cfg4"] = prune_mix_sweep(dev, dtype)
             line["dense_branch"] = dense_leg(dev, dtype)
+            if dtype == torch.bfloat16:
+                line["one_pass_kernel"] = one_pass_leg(dev)
         if not args.no_full_model and dtype == torch.bfloat16 and world == 1:  # a one-GPU measurement
             line["full_model_cfg2"] = full_model_leg(dev)
         if not args.no_cpu_baseline and world == 1:

@@ -708,3 +708,32 @@ def test_affine_sums_of_several_layers_in_one_launch(dev):
             for (a, b), (wa, wb) in zip(got, want):
                 np.testing.assert_allclose(a.cpu().numpy(), wa.cpu().numpy(), rtol=1e-5, atol=1e-5)
                 np.testing.assert_allclose(b.cpu().numpy(), wb.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_mean_ce_backward_with_a_scaled_incoming_gradient(dev):
+    """loss.backward() with a gradient other than the cached unit (a weighted or scaled loss): for bf16
+    logits the logits gradient is formed in f32 and rounded ONCE (the hand-over copy that the unit case
+    uses is already rounded to bf16 and must not be scaled and rounded again)."""
+    from vqa_amd import ops
+    B, C = 64, 430
+    lg = gi.normal(71, B, C).to(dev)
+    y = gi.labels(72, B, C).to(dev)
+    want = torch.softmax(lg.bfloat16().double(), -1)
+    want[torch.arange(B), y] -= 1.0
+    want = want * (2.0 / B)
+    for scale in (2.0, torch.tensor(2.0, device=dev)):
+        x = lg.bfloat16().requires_grad_()
+        loss = ops.cross_entropy_mean(x, y)
+        if isinstance(scale, float):
+            (loss * scale).backward()
+        else:
+            loss.backward(gradient=scale)
+        once = want.to(torch.bfloat16)  # the f64 gradient rounded once
+        diff = (x.grad.double() - once.double()).abs()
+        # identical to single rounding except where f32 vs f64 arithmetic lands on the other side of a tie
+        assert float((diff > 0).double().mean()) < 0.02
+        assert float((diff / (once.double().abs() + 1e-12)).max()) <= 2.0 ** -7
+    x = lg.bfloat16().requires_grad_()
+    loss = ops.cross_entropy_mean(x, y)
+    loss.backward(gradient=ops.unit_gradient(loss))
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), (want / 2).float().cpu().numpy(), rtol=2.0 ** -7, atol=1e-9)

@@ -582,3 +582,29 @@ def test_reference_order_scoring_mode(dev, name):
     m.score_order = "else"
     with pytest.raises(ValueError):
         m(v_seq.to(dev), v_global.to(dev), q_seq.to(dev), q_global.to(dev))
+
+
+def test_in_kernel_noise_against_torch_normal(dev):
+    """The token noise is built from 16-bit uniforms (65536 radii x 65536 angles, |z| <= 4.85 sigma)
+    where the reference calls torch.normal.  Two million draws of each: the empirical distribution
+    functions agree at every probed point within sampling error (a two-sample Kolmogorov-Smirnov
+    distance far below its 1 % critical value), as do the moments up to the fourth; what differs is the
+    mass beyond 4.85 sigma (1.2e-6 of the draws), which the kernel does not produce."""
+    from vqa_amd import ops
+    seq = torch.zeros(32, 130, 512, device=dev)
+    idx = torch.arange(128, device=dev).repeat(32, 1)
+    z = ops.gather_mix(seq, idx, 0.0, noise_type="gaussian", noise_scale=1.0, rng=ops.PhiloxState(dev, seed=19)).reshape(-1)
+    g = torch.Generator(device=dev).manual_seed(23)
+    t = torch.normal(0.0, 1.0, (z.numel(),), device=dev, generator=g)
+    n = z.numel()
+    pts = torch.linspace(-4.5, 4.5, 181, device=dev)
+    cdf = lambda x: (x.unsqueeze(0) <= pts.unsqueeze(1)).float().mean(1)  # noqa: E731
+    chunks = [slice(i, i + (1 << 18)) for i in range(0, n, 1 << 18)]
+    fz = sum(cdf(z[c]) * (c.stop - c.start if c.stop <= n else n - c.start) for c in chunks) / n
+    ft = sum(cdf(t[c]) * (c.stop - c.start if c.stop <= n else n - c.start) for c in chunks) / n
+    ks = float((fz - ft).abs().max())
+    assert ks < 1.63 * (2.0 / n) ** 0.5, ks        # 1 % critical value of the two-sample statistic
+    for p in (1, 2, 3, 4):
+        mz, mt = float((z.double() ** p).mean()), float((t.double() ** p).mean())
+        assert abs(mz - mt) < 6 * (105.0 / n) ** 0.5, (p, mz, mt)   # 105 = variance bound of z^4
+    assert float(z.abs().max()) <= 4.86

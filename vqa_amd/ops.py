@@ -713,6 +713,8 @@ class _MeanCE(torch.autograd.Function):
         loss, _, _, grad = ce_conf(logits, targets, want_loss=True, want_conf=False, grad_scale=1.0 / B, grad_dtype=gdt)
         ctx.save_for_backward(grad)
         ctx.in_dtype = logits.dtype
+        # kept for the rare backward with a non-unit incoming gradient (see backward); no copy is made
+        ctx.logits, ctx.targets = (logits.detach(), targets) if gdt != torch.float32 else (None, None)
         return loss.mean()
 
     @staticmethod
@@ -727,6 +729,13 @@ class _MeanCE(torch.autograd.Function):
             check(load().vqaf_scale_cast(ptr(grad), ptr(go), grad.numel(), dtype_code(out), ptr(out),
                                          stream_ptr(grad.device)), "vqaf_scale_cast")
             return out, None
+        # bf16 logits and another incoming gradient (a weighted or scaled loss): the saved gradient was
+        # rounded to bf16 for the unit-gradient hand-over, so scaling it would round twice; form it again
+        # from the logits in f32 and round the product once
+        if grad.dtype != torch.float32 and ctx.logits is not None:
+            _, _, _, g32 = ce_conf(ctx.logits, ctx.targets, want_loss=False, want_conf=False,
+                                   grad_scale=1.0 / grad.shape[0], grad_dtype=torch.float32)
+            return (g32 * grad_out.float()).to(ctx.in_dtype), None
         return (grad.float() * grad_out).to(ctx.in_dtype), None
 
 
