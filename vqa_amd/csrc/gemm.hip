@@ -136,6 +136,11 @@ gemm_f32_kernel(GemmSets sets, long a_sg, long a_sm, long a_sk, long b_sg, long 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  // a lane's sixteen outputs share one column: its bias is one value, fetched before the k loop
+  const int gn = n0 + wn * 32 + (lane & 31);
+  float bias_v = 0.f;
+  if (bias != nullptr && kz == 0 && gn < N)
+    bias_v = bias_bf16 ? load1<true>(bias, (size_t)((long)g * bias_sg + gn)) : load1<false>(bias, (size_t)((long)g * bias_sg + gn));
   const long abase = (long)g * a_sg, bbase = (long)g * b_sg;
   // register staging runs two stages ahead of the MFMAs (stage t lives in register set t & 1),
   // LDS is double buffered: the loads of stage s+2 are in flight while stage s is multiplied
@@ -159,33 +164,41 @@ gemm_f32_kernel(GemmSets sets, long a_sg, long a_sm, long a_sk, long b_sg, long 
       const int t = s + P;
       fetch_tile<AMODE, A_BF16>(A, abase, a_sm, a_sk, m0, M, k_lo + (t + 2) * GK, K, tid, ra[P]);
       fetch_tile<BMODE, B_BF16>(Bm, bbase, b_sn, b_sk, n0, N, k_lo + (t + 2) * GK, K, tid, rb[P]);
+      // all operand reads of the stage are issued before the first MFMA: one LDS latency per stage,
+      // not one per k pair
+      float af[GK / 2], bf[GK / 2];
 #pragma unroll
-      for (int kk = 0; kk < GK; kk += 2) {
-        const float af = As[P][kk + (lane >> 5)][wm * 32 + (lane & 31)];
-        const float bf = Bs[P][kk + (lane >> 5)][wn * 32 + (lane & 31)];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+      for (int i = 0; i < GK / 2; ++i) {
+        af[i] = As[P][2 * i + (lane >> 5)][wm * 32 + (lane & 31)];
+        bf[i] = Bs[P][2 * i + (lane >> 5)][wn * 32 + (lane & 31)];
       }
+      __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from sinking the reads back to their uses
+#pragma unroll
+      for (int i = 0; i < GK / 2; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[i], acc, 0, 0, 0);
       store_tile<AMODE, A_BF16>(As[P ^ 1], tid, ra[P ^ 1], m0, M, k_lo + (t + 1) * GK, K);
       store_tile<BMODE, B_BF16>(Bs[P ^ 1], tid, rb[P ^ 1], n0, N, k_lo + (t + 1) * GK, K);
       __syncthreads();
     }
   }
   // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* const c0 = C + (long)g * c_sg + gn;
+  const int gm0 = m0 + wm * 32 + 4 * (lane >> 5);
+  float prev[16];
+  if (beta_one && splits == 1) {  // the sixteen reads issue together
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gm = gm0 + (r & 3) + 8 * (r >> 2);
+      prev[r] = (gm < M && gn < N) ? c0[(long)gm * c_sm] : 0.f;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    const int gn = n0 + wn * 32 + (lane & 31);
+    const int gm = gm0 + (r & 3) + 8 * (r >> 2);
     if (gm < M && gn < N) {
-      float v = alpha * acc[r];
-      if (bias != nullptr && kz == 0)
-        v += bias_bf16 ? load1<true>(bias, (size_t)((long)g * bias_sg + gn)) : load1<false>(bias, (size_t)((long)g * bias_sg + gn));
-      float* c = C + (long)g * c_sg + gm * c_sm + gn;
-      if (splits > 1) {
-        atomicAdd(c, v);
-      } else {
-        if (beta_one) v += *c;
-        *c = v;
-      }
+      const float v = alpha * acc[r] + bias_v;
+      float* c = c0 + (long)gm * c_sm;
+      if (splits > 1) atomicAdd(c, v);
+      else *c = beta_one ? v + prev[r] : v;
     }
   }
 }
@@ -262,6 +275,176 @@ int gemm_launch(const GemmSets& sets, int nsets, int a_dtype, long a_sg, long a_
   VQAF_LAUNCH_CHECK();
 }
 
+
+// ---- Query fold with bf16 operands (bf16 queries, bf16 in_proj, head width 64, D = 512) on the bf16
+// matrix cores, one launch.  A product of two bf16 values is exact in f32, so
+//   qproj = q Wq_h^T + bq_h            (one bf16 MFMA per 32 k, f32 accumulation)
+// has f32 accuracy as it stands, and the second product keeps it by entering qproj as THREE bf16 terms
+// (8 + 8 + 8 mantissa bits: the split is exact) against the exact bf16 rows of Wk:
+//   u[b,h,:] = (qproj_hi + qproj_mid + qproj_lo)[b, h*64 : h*64+64] @ Wk[h*64 : h*64+64, :] / 8.
+// A workgroup owns 32 queries of one head: its 64 rows of Wk arrive in LDS by LDS-DMA (one 1 KiB row
+// per instruction) while the first product runs straight from global memory (both operands are
+// k-contiguous there, which is the MFMA's own fragment layout); the 32 x 64 qproj tile crosses to the
+// A-operand layout through LDS, and Wk is read back with the transposing LDS read.  Every sum has a
+// fixed order: the result does not vary from run to run (the scores rank tokens).
+constexpr int FQ_ROWS = 32, FQ_THREADS = 256, FQ_D = 512, FQ_DH = 64;
+constexpr int FQ_WP = (FQ_D + 8) * 2;  // bytes per staged Wk row (the pad spreads the transposing reads over banks)
+constexpr int FQ_PP = (FQ_DH + 8) * 2;  // bytes per row of a staged qproj term
+constexpr int FQ_PLANE = FQ_ROWS * FQ_PP;
+constexpr size_t FQ_LDS = (size_t)FQ_DH * FQ_WP + 3 * (size_t)FQ_PLANE;
+
+typedef __bf16 fq_frag __attribute__((ext_vector_type(8)));
+typedef short fq_s16x4 __attribute__((ext_vector_type(4)));
+
+struct FoldSets {
+  const bf16_t* q[GEMM_MAX_SETS];
+  const bf16_t* w[GEMM_MAX_SETS];
+  const bf16_t* bias[GEMM_MAX_SETS];
+  float* qproj[GEMM_MAX_SETS];
+  float* u[GEMM_MAX_SETS];
+};
+
+__device__ __forceinline__ fq_frag fq_as_frag(u32x4 v) {
+  union { u32x4 u; fq_frag f; } c;
+  c.u = v;
+  return c.f;
+}
+// Lane i of a 16-lane group points at row i / 4, columns 4 * (i % 4) .. + 3 of a 4 x 16 block of 16-bit
+// elements and receives column i of the four rows.
+__device__ __forceinline__ u32x2 fq_read_tr(const unsigned char* p) {
+  const fq_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) fq_s16x4*)(const_cast<unsigned char*>(p)));
+  union { fq_s16x4 s; u32x2 u; } c;
+  c.s = v;
+  return c.u;
+}
+// x = hi + mid + lo exactly, each term a bf16 (truncating splits of the 24-bit mantissa); writes the
+// three terms to the same element of the three planes.
+__device__ __forceinline__ void fq_split_store(float x, unsigned char* plane0_elem) {
+  const unsigned int hi = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(hi);
+  const unsigned int mid = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mid);
+  *reinterpret_cast<bf16_t*>(plane0_elem) = (bf16_t)(hi >> 16);
+  *reinterpret_cast<bf16_t*>(plane0_elem + FQ_PLANE) = (bf16_t)(mid >> 16);
+  *reinterpret_cast<bf16_t*>(plane0_elem + 2 * FQ_PLANE) = (bf16_t)(__float_as_uint(r2) >> 16);
+}
+
+__global__ void __launch_bounds__(FQ_THREADS)
+fold_query_bf16_kernel(FoldSets sets, int B, int H) {
+
+  constexpr int D = FQ_D;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fq_lds[];
+  unsigned char* Ws = fq_lds;                            // [64][FQ_WP] bf16 rows of Wk_h
+  unsigned char* Ps = fq_lds + (size_t)FQ_DH * FQ_WP;    // [3][32][FQ_PP] the qproj tile's hi / mid / lo terms
+  const int set = blockIdx.z, h = blockIdx.y, r0 = blockIdx.x * FQ_ROWS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const bf16_t* __restrict__ q = sets.q[set];
+  const bf16_t* __restrict__ w = sets.w[set];
+  const int col = 16 * wave + li;  // this lane's column of the head in the first product
+  const unsigned int bias_raw = sets.bias[set][h * FQ_DH + col];
+  // Wk rows of this head -> LDS; wave takes rows 16 * wave .. + 15
+  const bf16_t* wk = w + (size_t)(D + h * FQ_DH) * D;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int k = 16 * wave + r;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + (size_t)k * D + 8 * lane),
+                                     (__attribute__((address_space(3))) void*)(Ws + (size_t)k * FQ_WP), 16, 0, 0);
+  }
+  // first product: wave owns columns 16 * wave .. + 15 of the head, both 16-row tiles
+  f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
+  {
+    const bf16_t* a0 = q + (size_t)min(r0 + li, B - 1) * D + 8 * g;
+    const bf16_t* a1 = q + (size_t)min(r0 + 16 + li, B - 1) * D + 8 * g;
+    const bf16_t* bp = w + (size_t)(h * FQ_DH + col) * D + 8 * g;
+    // every fragment of the contraction is requested before the first product: one memory latency for
+    // the phase (the workgroup runs two waves per SIMD, so the registers are there)
+    fq_frag fa0[D / 32], fa1[D / 32], fb[D / 32];
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+      fb[s] = *reinterpret_cast<const fq_frag*>(bp + 32 * s);
+      fa0[s] = *reinterpret_cast<const fq_frag*>(a0 + 32 * s);
+      fa1[s] = *reinterpret_cast<const fq_frag*>(a1 + 32 * s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+      p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[s], fb[s], p0, 0, 0, 0);
+      p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[s], fb[s], p1, 0, 0, 0);
+    }
+    // accumulator layout: column = lane & 15, rows 4 * (lane >> 4) + r
+    const float bv = bf16_lo(bias_raw);
+    float* qp = sets.qproj[set];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v0 = p0[r] + bv, v1 = p1[r] + bv;
+      const int row = 4 * g + r;
+      fq_split_store(v0, Ps + row * FQ_PP + 2 * col);
+      fq_split_store(v1, Ps + (16 + row) * FQ_PP + 2 * col);
+      if (r0 + row < B) qp[(size_t)(r0 + row) * D + h * FQ_DH + col] = v0;
+      if (r0 + 16 + row < B) qp[(size_t)(r0 + 16 + row) * D + h * FQ_DH + col] = v1;
+    }
+  }
+  __syncthreads();  // also retires the LDS-DMA rows
+  // second product: A = the qproj tile's three terms, [term][row tile][k step]
+  fq_frag af[3][2][2];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        af[p][t][s] = *reinterpret_cast<const fq_frag*>(Ps + p * FQ_PLANE + (16 * t + li) * FQ_PP + (32 * s + 8 * g) * 2);
+  // wave owns output columns 128 * wave .. + 127 in eight tiles of 16
+  float* u = sets.u[set];
+  const float scale = 0.125f;  // 1 / sqrt(64)
+  const bool whole = r0 + FQ_ROWS <= B;  // uniform: the common case stores without per-row tests
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int colbase = 128 * wave + 16 * c;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const unsigned char* rd = Ws + (size_t)(32 * s + 8 * g + (li >> 2)) * FQ_WP + (colbase + 4 * (li & 3)) * 2;
+      const u32x2 b_lo = fq_read_tr(rd), b_hi = fq_read_tr(rd + 4 * FQ_WP);
+      const fq_frag fb = fq_as_frag(u32x4{b_lo.x, b_lo.y, b_hi.x, b_hi.y});
+#pragma unroll
+      for (int p = 2; p >= 0; --p) {  // smallest term first
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p][0][s], fb, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p][1][s], fb, o1, 0, 0, 0);
+      }
+    }
+    float* ur = u + ((size_t)(r0 + 4 * g) * H + h) * D + colbase + li;
+    if (whole) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ur[(size_t)r * H * D] = o0[r] * scale;
+        ur[(size_t)(r + 16) * H * D] = o1[r] * scale;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + 4 * g + r;
+        if (row < B) ur[(size_t)r * H * D] = o0[r] * scale;
+        if (row + 16 < B) ur[(size_t)(r + 16) * H * D] = o1[r] * scale;
+      }
+    }
+  }
+}
+
+bool fold_bf16_applies(int D, int H, int dtype, int w_dtype) {
+  return dtype == VQAF_BF16 && w_dtype == VQAF_BF16 && D == FQ_D && H * FQ_DH == D;
+}
+
+int fold_bf16_launch(const FoldSets& sets, int n, int B, int H, hipStream_t st) {
+  static int attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(fold_query_bf16_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)FQ_LDS);
+  if (attr_rc != hipSuccess) return VQAF_E_LAUNCH;
+  const dim3 grid((B + FQ_ROWS - 1) / FQ_ROWS, H, n), block(FQ_THREADS);
+  hipLaunchKernelGGL(fold_query_bf16_kernel, grid, block, FQ_LDS, st, sets, B, H);
+  VQAF_LAUNCH_CHECK();
+}
+
 }  // namespace
 
 extern "C" int vqaf_gemm_f32(const void* A, int a_dtype, long a_sg, long a_sm, long a_sk,
@@ -306,6 +489,23 @@ extern "C" int vqaf_fold_query_multi(const vqaf_fold_desc* descs_host, int n, in
   VQAF_REQUIRE(descs_host != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(n > 0 && n <= GEMM_MAX_SETS && B > 0 && D > 0 && H > 0 && D % H == 0, VQAF_E_SHAPE);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(w_dtype), VQAF_E_DTYPE);
+  bool fast = fold_bf16_applies(D, H, dtype, w_dtype);
+  for (int i = 0; i < n && fast; ++i)  // 16-byte fragment loads
+    fast = reinterpret_cast<uintptr_t>(descs_host[i].q) % 16 == 0 &&
+           reinterpret_cast<uintptr_t>(descs_host[i].in_proj_weight) % 16 == 0;
+  if (fast) {
+    FoldSets fs = {};
+    for (int i = 0; i < n; ++i) {
+      const vqaf_fold_desc& d = descs_host[i];
+      VQAF_REQUIRE(d.q && d.in_proj_weight && d.in_proj_bias && d.qproj_ws && d.u, VQAF_E_NULL);
+      fs.q[i] = static_cast<const bf16_t*>(d.q);
+      fs.w[i] = static_cast<const bf16_t*>(d.in_proj_weight);
+      fs.bias[i] = static_cast<const bf16_t*>(d.in_proj_bias);
+      fs.qproj[i] = d.qproj_ws;
+      fs.u[i] = d.u;
+    }
+    return fold_bf16_launch(fs, n, B, H, (hipStream_t)stream);
+  }
   const int dh = D / H;
   const size_t esz = vqaf_esize(w_dtype);
   GemmSets s1 = {}, s2 = {};

@@ -360,16 +360,9 @@ extern "C" int vqaf_fold_query(const void* q, const void* in_proj_weight, const 
   VQAF_REQUIRE(q && in_proj_weight && in_proj_bias && qproj_ws && u, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(w_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && D > 0 && H > 0 && D % H == 0, VQAF_E_SHAPE);
-  const int dh = D / H;
-  // qproj (B,D) = q Wq^T + bq
-  int rc = vqaf_gemm_f32(q, dtype, 0, D, 1, in_proj_weight, w_dtype, 0, 1, D, in_proj_bias, w_dtype,
-                         0, qproj_ws, 0, D, 1, B, D, D, 1.0f, 0, stream);
-  if (rc != VQAF_OK) return rc;
-  // u[b,h,:] = (1/sqrt(dh)) * qproj[b, h*dh:(h+1)*dh] @ Wk[h*dh:(h+1)*dh, :]
-  const size_t esz = vqaf_esize(w_dtype);
-  const void* wk = reinterpret_cast<const unsigned char*>(in_proj_weight) + (size_t)D * D * esz;
-  return vqaf_gemm_f32(qproj_ws, VQAF_F32, dh, D, 1, wk, w_dtype, (long)dh * D, D, 1, nullptr, 0, 0,
-                       u, D, (long)H * D, H, B, D, dh, 1.0f / sqrtf((float)dh), 0, stream);
+  // qproj (B,D) = q Wq^T + bq;  u[b,h,:] = (1/sqrt(dh)) * qproj[b, h*dh:(h+1)*dh] @ Wk[h*dh:(h+1)*dh, :]
+  const vqaf_fold_desc d = {q, in_proj_weight, in_proj_bias, qproj_ws, u};
+  return vqaf_fold_query_multi(&d, 1, B, D, H, dtype, w_dtype, stream);
 }
 
 static int launch_scores_mfma(const ScoreMods& mods, int n, int B, int Nmax, int D, int H, hipStream_t st);
