@@ -532,6 +532,16 @@ int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, int C, int d
                  float* loss, float* conf, int64_t* pred, void* grad_logits, int grad_dtype,
                  float grad_scale, vqaf_stream_t stream);
 
+/* The training loss of utils/src.py:96 (nn.CrossEntropyLoss(), mean over the batch) in ONE launch:
+ * vqaf_ce_conf's per-row losses `loss` (B) and logits gradient, plus their mean in loss_mean[0].  The
+ * workgroup that finishes last adds the B values in a fixed order (the result is the same whichever
+ * workgroup that is).  `ticket` is one zero-initialised 32-bit word of device memory owned by the caller;
+ * the launch leaves it zero, so it can be reused by the next call on the same stream (calls that overlap
+ * on different streams need a word each).  A target outside [0, C) makes the mean NaN. */
+int vqaf_ce_mean(const void* logits, const int64_t* targets, int B, int C, int dtype, float* loss,
+                 void* grad_logits, int grad_dtype, float grad_scale, float* loss_mean,
+                 unsigned int* ticket, vqaf_stream_t stream);
+
 /* out[i] = in[i] * scale[0] (scale in device memory), written as `out_dtype`: the backward of the
  * mean cross-entropy of utils/src.py:96 -- the logits gradient vqaf_ce_conf produced in the forward
  * pass times the incoming scalar gradient, rounded once into the logits' dtype. */

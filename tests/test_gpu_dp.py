@@ -737,3 +737,20 @@ def test_mean_ce_backward_with_a_scaled_incoming_gradient(dev):
     loss = ops.cross_entropy_mean(x, y)
     loss.backward(gradient=ops.unit_gradient(loss))
     np.testing.assert_allclose(x.grad.float().cpu().numpy(), (want / 2).float().cpu().numpy(), rtol=2.0 ** -7, atol=1e-9)
+
+
+def test_mean_ce_value_in_one_launch(dev):
+    """The mean of the per-row losses comes out of the same launch (last workgroup, fixed order): equal to
+    the float64 mean within f32 rounding, identical on repeated calls (the ticket word resets itself),
+    for batches that fill the last workgroup or not, rows cached in registers (C <= 512) or not."""
+    from vqa_amd import ops
+    for B, C in ((1, 3), (5, 430), (64, 430), (1023, 430), (130, 1000)):
+        lg = gi.normal(B + C, B, C, scale=3.0)
+        y = gi.labels(B, B, C)
+        want = float(fo.per_sample_ce(lg, y).double().mean())
+        got = [float(ops.cross_entropy_mean(lg.to(dev), y.to(dev))) for _ in range(3)]
+        assert got[0] == got[1] == got[2]
+        assert abs(got[0] - want) <= 2e-6 * max(1.0, abs(want))
+        lb = lg.bfloat16()
+        wb = float(fo.per_sample_ce(lb.float(), y).double().mean())
+        assert abs(float(ops.cross_entropy_mean(lb.to(dev), y.to(dev))) - wb) <= 2e-6 * max(1.0, abs(wb))

@@ -82,65 +82,99 @@ struct GhostLayers {
   int kind[GC_MAX_LAYERS];  // 0 Linear without bias, 1 Linear with bias, 2 affine
   int n;
 };
+// The layers' partial sums stay in registers until ONE block reduction at the end (no barrier between
+// layers, so the rows of different layers are in flight together), and the in-place scaling moves 16
+// bytes per lane where the row pitch allows it.  Few registers on purpose: eight workgroups share a
+// compute unit and cover each other's memory latency.
 template <bool BF16>
 __global__ void __launch_bounds__(DP_THREADS)
 ghost_clip_kernel(GhostLayers L, float max_norm, float scale, int scale_g, float* __restrict__ coef,
                   float* __restrict__ norms, float* __restrict__ sq_out) {
-  __shared__ float red[DP_THREADS / 64];
+  constexpr int NW = DP_THREADS / 64, SPAN = DP_THREADS * 8;
+  __shared__ float red[NW][2 * GC_MAX_LAYERS];
   __shared__ float s_coef;
-  const int b = blockIdx.x;
-  float total = 0.f;
-  for (int l = 0; l < L.n; ++l) {
-    const int In = L.in_dim[l], Out = L.out_dim[l];
-    if (L.kind[l] == 2) {
-      float s = 0.f;
-      for (int i = threadIdx.x * 8; i < Out; i += DP_THREADS * 8) {
-        float gv[8], xv[8];
-        load8<BF16>(L.g[l], (size_t)b * Out + i, gv);
-        load8<BF16>(L.a[l], (size_t)b * Out + i, xv);
+  const int b = blockIdx.x, tid = threadIdx.x, i0 = tid * 8;
+  // per-thread partial sums: [2l] = ||a||^2 part (Linear) or the whole affine term, [2l+1] = ||g||^2 part
+  float part[2 * GC_MAX_LAYERS];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xg = xv[e] * gv[e];
-          s = fmaf(xg, xg, s);
-          s = fmaf(gv[e], gv[e], s);
-        }
-      }
-      total += block_sum(s, red);
-    } else {
-      float na = 0.f, ng = 0.f;
-      // 16-byte loads where the row pitch keeps them aligned, element loads otherwise
-      if (In % 8 == 0 && vqaf_dev_aligned16(L.a[l])) {
-        for (int i = threadIdx.x * 8; i < In; i += DP_THREADS * 8) {
-          float v[8];
-          load8<BF16>(L.a[l], (size_t)b * In + i, v);
+  for (int l = 0; l < GC_MAX_LAYERS; ++l) {
+    float s0 = 0.f, s1 = 0.f;
+    if (l < L.n) {
+      const int Out = L.out_dim[l];
+      const bool vg = Out % 8 == 0 && vqaf_dev_aligned16(L.g[l]);
+      if (L.kind[l] == 2) {
+        if (vg && vqaf_dev_aligned16(L.a[l])) {
+          for (int i = i0; i < Out; i += SPAN) {
+            float gv[8], xv[8];
+            load8<BF16>(L.g[l], (size_t)b * Out + i, gv);
+            load8<BF16>(L.a[l], (size_t)b * Out + i, xv);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) na = fmaf(v[e], v[e], na);
+            for (int e = 0; e < 8; ++e) {
+              const float xg = xv[e] * gv[e];
+              s0 = fmaf(xg, xg, s0);
+              s0 = fmaf(gv[e], gv[e], s0);
+            }
+          }
+        } else {
+          for (int i = tid; i < Out; i += DP_THREADS) {
+            const float gv = load1<BF16>(L.g[l], (size_t)b * Out + i);
+            const float xg = load1<BF16>(L.a[l], (size_t)b * Out + i) * gv;
+            s0 = fmaf(xg, xg, s0);
+            s0 = fmaf(gv, gv, s0);
+          }
         }
       } else {
-        for (int i = threadIdx.x; i < In; i += DP_THREADS) {
-          const float v = load1<BF16>(L.a[l], (size_t)b * In + i);
-          na = fmaf(v, v, na);
-        }
-      }
-      if (Out % 8 == 0 && vqaf_dev_aligned16(L.g[l])) {
-        for (int i = threadIdx.x * 8; i < Out; i += DP_THREADS * 8) {
-          float v[8];
-          load8<BF16>(L.g[l], (size_t)b * Out + i, v);
+        const int In = L.in_dim[l];
+        if (In % 8 == 0 && vqaf_dev_aligned16(L.a[l])) {
+          for (int i = i0; i < In; i += SPAN) {
+            float v[8];
+            load8<BF16>(L.a[l], (size_t)b * In + i, v);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ng = fmaf(v[e], v[e], ng);
+            for (int e = 0; e < 8; ++e) s0 = fmaf(v[e], v[e], s0);
+          }
+        } else {
+          for (int i = tid; i < In; i += DP_THREADS) {
+            const float v = load1<BF16>(L.a[l], (size_t)b * In + i);
+            s0 = fmaf(v, v, s0);
+          }
         }
-      } else {
-        for (int i = threadIdx.x; i < Out; i += DP_THREADS) {
-          const float v = load1<BF16>(L.g[l], (size_t)b * Out + i);
-          ng = fmaf(v, v, ng);
+        if (vg) {
+          for (int i = i0; i < Out; i += SPAN) {
+            float v[8];
+            load8<BF16>(L.g[l], (size_t)b * Out + i, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s1 = fmaf(v[e], v[e], s1);
+          }
+        } else {
+          for (int i = tid; i < Out; i += DP_THREADS) {
+            const float v = load1<BF16>(L.g[l], (size_t)b * Out + i);
+            s1 = fmaf(v, v, s1);
+          }
         }
       }
-      na = block_sum(na, red);
-      ng = block_sum(ng, red);
-      total += na * ng + (L.kind[l] == 1 ? ng : 0.f);
+    }
+    part[2 * l] = s0;
+    part[2 * l + 1] = s1;
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int j = 0; j < 2 * GC_MAX_LAYERS; ++j) {
+    if (j < 2 * L.n) {
+      const float w = wave_sum(part[j]);
+      if (lane == 0) red[wave][j] = w;
     }
   }
-  if (threadIdx.x == 0) {
+  __syncthreads();
+  if (tid == 0) {
+    float total = 0.f;
+    for (int l = 0; l < L.n; ++l) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int w = 0; w < NW; ++w) {
+        s0 += red[w][2 * l];
+        s1 += red[w][2 * l + 1];
+      }
+      total += L.kind[l] == 2 ? s0 : s0 * s1 + (L.kind[l] == 1 ? s1 : 0.f);
+    }
     const float n = scale * sqrtf(total);
     const float c = scale * fminf(1.0f, max_norm / (n + 1e-6f));
     coef[b] = c;
@@ -149,15 +183,25 @@ ghost_clip_kernel(GhostLayers L, float max_norm, float scale, int scale_g, float
     if (sq_out != nullptr) sq_out[b] = total;
   }
   if (!scale_g) return;
-  // g_b <- coef_b * g_b for every layer, in place (the rows were just read, so they are cache
-  // hot): the clipped-sum kernels then run with coef == NULL, as plain batch contractions.
+  // g_b <- coef_b * g_b for every layer, in place (the rows were just read, so they are cache hot):
+  // the clipped-sum kernels then run with coef == NULL, as plain batch contractions.
   __syncthreads();
   const float c = s_coef;
   for (int l = 0; l < L.n; ++l) {
     const int Out = L.out_dim[l];
     void* gl = const_cast<void*>(L.g[l]);
-    for (int i = threadIdx.x; i < Out; i += DP_THREADS)
-      store1<BF16>(gl, (size_t)b * Out + i, c * load1<BF16>(gl, (size_t)b * Out + i));
+    if (Out % 8 == 0 && vqaf_dev_aligned16(gl)) {
+      for (int i = i0; i < Out; i += SPAN) {
+        float v[8];
+        load8<BF16>(gl, (size_t)b * Out + i, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= c;
+        store8<BF16>(gl, (size_t)b * Out + i, v);
+      }
+    } else {
+      for (int i = tid; i < Out; i += DP_THREADS)
+        store1<BF16>(gl, (size_t)b * Out + i, c * load1<BF16>(gl, (size_t)b * Out + i));
+    }
   }
 }
 
@@ -841,41 +885,115 @@ groupnorm_bwd_kernel(const void* __restrict__ grad_y, const void* __restrict__ y
   }
 }
 
-// One wave per row of logits.
+// One wave per row of logits.  Rows of up to 512 classes are read once and stay in registers for the
+// three uses (maximum, normaliser, gradient).  With loss_mean the launch also returns the mean of the
+// per-row losses: the last workgroup to finish (a ticket counter that it resets) adds the B values in
+// a fixed order, so the mean does not depend on which workgroup that was.
+constexpr int CE_REG = 8;
 template <bool BF16, bool GBF16>
 __global__ void __launch_bounds__(DP_THREADS)
 ce_conf_kernel(const void* __restrict__ logits, const int64_t* __restrict__ targets, int B, int C,
                float* __restrict__ loss, float* __restrict__ conf, int64_t* __restrict__ pred,
-               void* __restrict__ grad_logits, float grad_scale) {
+               void* __restrict__ grad_logits, float grad_scale, float* __restrict__ loss_mean,
+               unsigned int* __restrict__ ticket) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (DP_THREADS / 64) + (threadIdx.x >> 6);
-  if (b >= B) return;
-  float m = -INFINITY;
-  int am = 0x7fffffff;  // lowest index wins among equal maxima
-  for (int c = lane; c < C; c += 64) {
-    const float v = load1<BF16>(logits, (size_t)b * C + c);
-    if (v > m) { m = v; am = c; }
-  }
+  if (b < B) {
+    const bool cached = C <= 64 * CE_REG;
+    const int64_t t = targets != nullptr ? targets[b] : -1;  // requested first: nothing below waits on it alone
+    float v[CE_REG];
+    float xt = 0.f;  // the target's logit (cached rows: picked out of the registers)
+    float m = -INFINITY;
+    int am = 0x7fffffff;  // lowest index wins among equal maxima
+    if (cached) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float om = __shfl_xor(m, o, 64);
-    const int oa = __shfl_xor(am, o, 64);
-    if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+      for (int i = 0; i < CE_REG; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < C ? load1<BF16>(logits, (size_t)b * C + c) : -INFINITY;
+      }
+#pragma unroll
+      for (int i = 0; i < CE_REG; ++i) {
+        if (v[i] > m) { m = v[i]; am = lane + 64 * i; }
+        if ((int64_t)(lane + 64 * i) == t) xt = v[i];
+      }
+      xt = wave_sum(xt);  // one lane holds it, the others hold zero
+    } else {
+      for (int c = lane; c < C; c += 64) {
+        const float x = load1<BF16>(logits, (size_t)b * C + c);
+        if (x > m) { m = x; am = c; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(m, o, 64);
+      const int oa = __shfl_xor(am, o, 64);
+      if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
+    float z = 0.f;
+    if (cached) {
+#pragma unroll
+      for (int i = 0; i < CE_REG; ++i) {
+        v[i] = expf(v[i] - m);  // exp(-inf) = 0 for the columns past C
+        z += v[i];
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) z += expf(load1<BF16>(logits, (size_t)b * C + c) - m);
+    }
+    z = wave_sum(z);
+    if (lane == 0) {
+      if (loss != nullptr) {
+        if (t >= 0 && t < C) loss[b] = (m + logf(z)) - (cached ? xt : load1<BF16>(logits, (size_t)b * C + t));
+        else if (loss_mean != nullptr) loss[b] = NAN;
+      }
+      if (conf != nullptr) conf[b] = 1.0f / z;
+      if (pred != nullptr) pred[b] = (int64_t)(am == 0x7fffffff ? 0 : am);
+    }
+    if (grad_logits != nullptr) {
+      if (cached) {
+#pragma unroll
+        for (int i = 0; i < CE_REG; ++i) {
+          const int c = lane + 64 * i;
+          if (c < C) store1<GBF16>(grad_logits, (size_t)b * C + c, grad_scale * (v[i] / z - ((int64_t)c == t ? 1.f : 0.f)));
+        }
+      } else {
+        for (int c = lane; c < C; c += 64) {
+          const float p = expf(load1<BF16>(logits, (size_t)b * C + c) - m) / z;
+          store1<GBF16>(grad_logits, (size_t)b * C + c, grad_scale * (p - ((int64_t)c == t ? 1.f : 0.f)));
+        }
+      }
+    }
   }
-  float z = 0.f;
-  for (int c = lane; c < C; c += 64) z += expf(load1<BF16>(logits, (size_t)b * C + c) - m);
-  z = wave_sum(z);
-  const int64_t t = targets != nullptr ? targets[b] : -1;
-  if (lane == 0) {
-    if (loss != nullptr && t >= 0 && t < C)
-      loss[b] = (m + logf(z)) - load1<BF16>(logits, (size_t)b * C + t);
-    if (conf != nullptr) conf[b] = 1.0f / z;
-    if (pred != nullptr) pred[b] = (int64_t)(am == 0x7fffffff ? 0 : am);
+  if (loss_mean == nullptr) return;  // uniform
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
   }
-  if (grad_logits != nullptr) {
-    for (int c = lane; c < C; c += 64) {
-      const float p = expf(load1<BF16>(logits, (size_t)b * C + c) - m) / z;
-      store1<GBF16>(grad_logits, (size_t)b * C + c, grad_scale * (p - ((int64_t)c == t ? 1.f : 0.f)));
+  __syncthreads();
+  if (s_last) {
+    // thread t adds rows t, t + 256, ... (four requests in flight at a time), waves and threads are
+    // combined in index order
+    __shared__ float s_part[DP_THREADS / 64];
+    __threadfence();
+    float s = 0.f;
+    int i = threadIdx.x;
+    for (; i + 3 * DP_THREADS < B; i += 4 * DP_THREADS) {
+      const float x0 = __hip_atomic_load(loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float x1 = __hip_atomic_load(loss + i + DP_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float x2 = __hip_atomic_load(loss + i + 2 * DP_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float x3 = __hip_atomic_load(loss + i + 3 * DP_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s += (x0 + x1) + (x2 + x3);
+    }
+    for (; i < B; i += DP_THREADS) s += __hip_atomic_load(loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = wave_sum(s);
+    if (lane == 0) s_part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < DP_THREADS / 64; ++w) t += s_part[w];
+      *loss_mean = t / (float)B;
+      *ticket = 0u;
     }
   }
 }
@@ -1214,23 +1332,38 @@ extern "C" int vqaf_groupnorm_bwd(const void* grad_y, const void* y, const void*
   VQAF_LAUNCH_CHECK();
 }
 
-extern "C" int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, int C, int dtype,
-                            float* loss, float* conf, int64_t* pred, void* grad_logits, int grad_dtype,
-                            float grad_scale, vqaf_stream_t stream) {
-  VQAF_ENTRY();
+static int ce_launch(const void* logits, const int64_t* targets, int B, int C, int dtype, float* loss, float* conf,
+                     int64_t* pred, void* grad_logits, int grad_dtype, float grad_scale, float* loss_mean,
+                     unsigned int* ticket, hipStream_t st) {
   VQAF_REQUIRE(logits != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE((loss == nullptr && grad_logits == nullptr) || targets != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype) && (grad_logits == nullptr || vqaf_dtype_ok(grad_dtype)), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && C > 0, VQAF_E_SHAPE);
   const int rows_per_block = DP_THREADS / 64;
   const dim3 grid((B + rows_per_block - 1) / rows_per_block), block(DP_THREADS);
-  hipStream_t st = (hipStream_t)stream;
-#define VQAF_CE(LB, GB) hipLaunchKernelGGL((ce_conf_kernel<LB, GB>), grid, block, 0, st, logits, targets, B, C, loss, conf, pred, grad_logits, grad_scale)
+#define VQAF_CE(LB, GB) hipLaunchKernelGGL((ce_conf_kernel<LB, GB>), grid, block, 0, st, logits, targets, B, C, loss, conf, pred, grad_logits, grad_scale, loss_mean, ticket)
   const bool gb = grad_logits != nullptr && grad_dtype == VQAF_BF16;
   if (dtype == VQAF_BF16) { if (gb) VQAF_CE(true, true); else VQAF_CE(true, false); }
   else { if (gb) VQAF_CE(false, true); else VQAF_CE(false, false); }
 #undef VQAF_CE
   VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, int C, int dtype,
+                            float* loss, float* conf, int64_t* pred, void* grad_logits, int grad_dtype,
+                            float grad_scale, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  return ce_launch(logits, targets, B, C, dtype, loss, conf, pred, grad_logits, grad_dtype, grad_scale, nullptr,
+                   nullptr, (hipStream_t)stream);
+}
+
+extern "C" int vqaf_ce_mean(const void* logits, const int64_t* targets, int B, int C, int dtype, float* loss,
+                            void* grad_logits, int grad_dtype, float grad_scale, float* loss_mean,
+                            unsigned int* ticket, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(loss != nullptr && loss_mean != nullptr && ticket != nullptr && targets != nullptr, VQAF_E_NULL);
+  return ce_launch(logits, targets, B, C, dtype, loss, nullptr, nullptr, grad_logits, grad_dtype, grad_scale,
+                   loss_mean, ticket, (hipStream_t)stream);
 }
 
 extern "C" int vqaf_scale_cast(const float* in, const float* scale, size_t n, int out_dtype, void* out,

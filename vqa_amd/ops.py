@@ -701,6 +701,9 @@ def ce_conf(logits: torch.Tensor, targets: Optional[torch.Tensor] = None, want_l
     return loss, conf, pred, grad
 
 
+_ce_tickets: dict = {}
+
+
 class _MeanCE(torch.autograd.Function):
     """Mean cross-entropy (nn.CrossEntropyLoss() as the training loop uses it, train.py:104,
     utils/src.py:96) with its logits gradient produced by the same kernel launch."""
@@ -710,12 +713,28 @@ class _MeanCE(torch.autograd.Function):
         B = logits.shape[0]
         # the gradient is written in the logits' dtype: with the usual incoming gradient of 1 it is handed on as is
         gdt = logits.dtype if logits.dtype in (torch.float32, torch.bfloat16) else torch.float32
-        loss, _, _, grad = ce_conf(logits, targets, want_loss=True, want_conf=False, grad_scale=1.0 / B, grad_dtype=gdt)
+        lg = logits.contiguous()
+        dev = lg.device
+        C = lg.shape[1]
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        grad = torch.empty(B, C, dtype=gdt, device=dev)
+        mean = torch.empty((), dtype=torch.float32, device=dev)
+        # one self-resetting ticket word per device, made before any graph capture can be under way (a
+        # tensor allocated during a capture would live in that graph's memory pool); mean losses computed
+        # on different streams of one device must not overlap
+        ticket = _ce_tickets.get(dev)
+        if ticket is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("cross_entropy_mean: run one step eagerly before capturing a HIP graph")
+            ticket = _ce_tickets[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(load().vqaf_ce_mean(ptr(lg), ptr(targets.to(torch.int64).contiguous()), B, C, dtype_code(lg), ptr(loss),
+                                  ptr(grad), dtype_code(grad), 1.0 / B, ptr(mean), ptr(ticket), stream_ptr(dev)),
+              "vqaf_ce_mean")
         ctx.save_for_backward(grad)
         ctx.in_dtype = logits.dtype
         # kept for the rare backward with a non-unit incoming gradient (see backward); no copy is made
         ctx.logits, ctx.targets = (logits.detach(), targets) if gdt != torch.float32 else (None, None)
-        return loss.mean()
+        return mean
 
     @staticmethod
     def backward(ctx, grad_out):
