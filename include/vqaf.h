@@ -393,8 +393,10 @@ int vqaf_gemm_f32_atomic(const void* A, int a_dtype, long a_sg, long a_sm, long 
  * C; accumulate != 0 adds into an f32 C (and colsum).  Few output tiles with an f32 C split the contraction over workgroups
  * and add partial tiles with f32 atomics (summation order then varies from run to run).
  * vqaf_gemm_bf16_supported tells whether the layout is covered: row pitches multiples of 8
- * elements, a k-contiguous operand needs K % 8 == 0, a k-major operand needs its row pitch to
- * cover the row count rounded up to 8; otherwise VQAF_E_ALIGN (use another GEMM). */
+ * elements; a k-contiguous operand needs its row pitch to cover K rounded up to 8, and when K is not
+ * a multiple of 8 its elements between K and that bound must be ZERO and the other operand must be
+ * k-major (its rows past K are never read); a k-major operand needs its row pitch to cover the row
+ * count rounded up to 8; otherwise VQAF_E_ALIGN (use another GEMM). */
 int vqaf_gemm_bf16_supported(long lda, int a_kmajor, long ldb, int b_kmajor, int M, int N, int K);
 int vqaf_gemm_bf16(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int M, int N,
                    int K, const void* bias, int bias_dtype, void* C, long ldc, int c_dtype, int accumulate,
@@ -403,9 +405,9 @@ int vqaf_gemm_bf16(const void* A, long lda, int a_kmajor, const void* B, long ld
 /* n <= 4 products of the clipped-sum shape in ONE launch: C_i (M_i,N_i) f32 = A_i^T B_i with A_i (K,M_i) and
  * B_i (K,N_i) bf16, both k-major, the same K (the batch); colsum (array of n pointers, or NULL, entries may be
  * NULL) receives the column sums of A_i; accumulate != 0 adds into C_i / colsum_i.  The clipped sums of the
- * classifier's Linear layers are launch-bound on their own.  Returns VQAF_E_SHAPE when a product has fewer than
- * 192 output tiles (it wants its contraction split) or the products need different tile heights: the caller
- * then uses vqaf_gemm_bf16 per product. */
+ * classifier's Linear layers are launch-bound on their own.  Returns VQAF_E_SHAPE when the launch would have
+ * fewer than 192 output tiles altogether (such products want their contraction split) or the products need
+ * different tile heights: the caller then uses vqaf_gemm_bf16 per product. */
 int vqaf_gemm_bf16_wgrad_group(int n, const void* const* A, const long* lda, const void* const* B,
                                const long* ldb, const int* M, const int* N, int K, float* const* C,
                                const long* ldc, int accumulate, float* const* colsum, vqaf_stream_t stream);
@@ -537,9 +539,12 @@ int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, int C, int d
  * workgroup that finishes last adds the B values in a fixed order (the result is the same whichever
  * workgroup that is).  `ticket` is one zero-initialised 32-bit word of device memory owned by the caller;
  * the launch leaves it zero, so it can be reused by the next call on the same stream (calls that overlap
- * on different streams need a word each).  A target outside [0, C) makes the mean NaN. */
+ * on different streams need a word each).  A target outside [0, C) makes the mean NaN.  grad_logits rows
+ * are ld_grad >= C elements apart and the launch writes zeros to the elements between C and ld_grad: with
+ * ld_grad = C rounded up to 8 the gradient of a 430-class head is a legal operand of vqaf_gemm_bf16 and of
+ * vqaf_gemm_bf16_wgrad_group. */
 int vqaf_ce_mean(const void* logits, const int64_t* targets, int B, int C, int dtype, float* loss,
-                 void* grad_logits, int grad_dtype, float grad_scale, float* loss_mean,
+                 void* grad_logits, long ld_grad, int grad_dtype, float grad_scale, float* loss_mean,
                  unsigned int* ticket, vqaf_stream_t stream);
 
 /* out[i] = in[i] * scale[0] (scale in device memory), written as `out_dtype`: the backward of the

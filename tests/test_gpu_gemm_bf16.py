@@ -123,8 +123,42 @@ def test_wgrad_group_equals_single_launches(dev):
     assert ops.gemm_bf16_wgrad_group(items[:2], K, accumulate=True)
     np.testing.assert_allclose(items[0][2].cpu().numpy(), 2 * wants[0][0].numpy(), rtol=1e-5,
                                atol=6e-6 * float(wants[0][0].abs().max()))
-    # a narrow product (few tiles: wants its contraction split) cannot join
-    A, _ = _operand(41, K, 256, 256, dev)
-    B, _ = _operand(42, K, 128, 128, dev)
-    C = torch.zeros(256, 128, device=dev)
-    assert ops.gemm_bf16_wgrad_group([items[0], (A, B, C, None)], K) is False
+    # a narrow product joins a launch that fills the chip without it (the 430-wide head beside the wide layers:
+    # row pitch 432, the rows' padding zero) and equals its own launch up to the split contraction of the latter
+    Ap = torch.zeros(K, 432, device=dev, dtype=torch.bfloat16)
+    Ap[:, :430] = (torch.randn(K, 430, device=dev, generator=torch.Generator(device=dev).manual_seed(5)) * 0.1).bfloat16()
+    A = Ap[:, :430]
+    B, Bh = _operand(42, K, 1024, 1024, dev)
+    C = torch.full((430, 1024), float("nan"), device=dev)
+    cs = torch.full((430,), float("nan"), device=dev)
+    assert ops.gemm_bf16_wgrad_group([items[0], (A, B, C, cs)], K)
+    want = A.double().cpu().t() @ Bh.double()
+    np.testing.assert_allclose(C.cpu().numpy(), want.numpy(), rtol=1e-5, atol=3e-6 * float(want.abs().max()))
+    np.testing.assert_allclose(cs.cpu().numpy(), A.double().cpu().sum(0).numpy(), rtol=1e-5, atol=1e-5)
+    # too few tiles altogether (the products want their contraction split): refused, nothing launched
+    A2, _ = _operand(41, K, 256, 256, dev)
+    B2, _ = _operand(43, K, 128, 128, dev)
+    C2 = torch.zeros(256, 128, device=dev)
+    assert ops.gemm_bf16_wgrad_group([(A2, B2, C2, None), (A2, B2, C2, None)], K) is False
+    assert float(C2.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_dgrad_with_a_contraction_that_is_not_a_multiple_of_8(dev):
+    """The 430-class head's input gradient gx = gy W: gy rows padded with zeros to 432 elements are read in
+    whole 16-byte chunks, W's rows past 430 are never read (they come from the block of zeros)."""
+    from vqa_amd import ops
+    M, N, K = 200, 1024, 430
+    gen = torch.Generator(device=dev).manual_seed(9)
+    buf = torch.zeros(M, 432, device=dev, dtype=torch.bfloat16)
+    buf[:, :K] = torch.randn(M, K, device=dev, generator=gen).bfloat16()
+    gy = buf[:, :K]
+    # W is the LAST allocation-sized block here: junk or unmapped memory past its 430 rows must not matter
+    W = torch.randn(K, N, device=dev, generator=gen).bfloat16()
+    assert ops.gemm_bf16_supported(gy.stride(0), False, N, True, M, N, K)
+    assert not ops.gemm_bf16_supported(K, False, N, True, M, N, K)          # unpadded rows: refused
+    assert not ops.gemm_bf16_supported(432, False, 432, False, M, N, K)     # both k-contiguous: refused
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm_bf16(gy, False, W, True, M, N, K, out)
+    want = gy.double() @ W.double()
+    np.testing.assert_allclose(out.double().cpu().numpy(), want.cpu().numpy(), rtol=2.0 ** -7, atol=2e-2)

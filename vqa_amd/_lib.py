@@ -131,7 +131,7 @@ SIGNATURES = {
     "vqaf_groupnorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P,
                                    _P]),
     "vqaf_ce_conf": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P]),
-    "vqaf_ce_mean": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, _P, _P]),
+    "vqaf_ce_mean": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_long, c_int, c_float, _P, _P, _P]),
     "vqaf_scale_cast": (c_int, [_P, _P, c_size_t, c_int, _P, _P]),
     "vqaf_attn_fwd": (c_int, [_P, _P, _P, c_long, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, c_long,
                               _P, _P]),

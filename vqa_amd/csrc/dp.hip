@@ -894,7 +894,7 @@ template <bool BF16, bool GBF16>
 __global__ void __launch_bounds__(DP_THREADS)
 ce_conf_kernel(const void* __restrict__ logits, const int64_t* __restrict__ targets, int B, int C,
                float* __restrict__ loss, float* __restrict__ conf, int64_t* __restrict__ pred,
-               void* __restrict__ grad_logits, float grad_scale, float* __restrict__ loss_mean,
+               void* __restrict__ grad_logits, long ldg, float grad_scale, float* __restrict__ loss_mean,
                unsigned int* __restrict__ ticket) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (DP_THREADS / 64) + (threadIdx.x >> 6);
@@ -953,14 +953,15 @@ ce_conf_kernel(const void* __restrict__ logits, const int64_t* __restrict__ targ
 #pragma unroll
         for (int i = 0; i < CE_REG; ++i) {
           const int c = lane + 64 * i;
-          if (c < C) store1<GBF16>(grad_logits, (size_t)b * C + c, grad_scale * (v[i] / z - ((int64_t)c == t ? 1.f : 0.f)));
+          if (c < C) store1<GBF16>(grad_logits, (size_t)b * ldg + c, grad_scale * (v[i] / z - ((int64_t)c == t ? 1.f : 0.f)));
         }
       } else {
         for (int c = lane; c < C; c += 64) {
           const float p = expf(load1<BF16>(logits, (size_t)b * C + c) - m) / z;
-          store1<GBF16>(grad_logits, (size_t)b * C + c, grad_scale * (p - ((int64_t)c == t ? 1.f : 0.f)));
+          store1<GBF16>(grad_logits, (size_t)b * ldg + c, grad_scale * (p - ((int64_t)c == t ? 1.f : 0.f)));
         }
       }
+      for (int c = C + lane; c < ldg; c += 64) store1<GBF16>(grad_logits, (size_t)b * ldg + c, 0.f);  // row padding
     }
   }
   if (loss_mean == nullptr) return;  // uniform
@@ -1333,15 +1334,15 @@ extern "C" int vqaf_groupnorm_bwd(const void* grad_y, const void* y, const void*
 }
 
 static int ce_launch(const void* logits, const int64_t* targets, int B, int C, int dtype, float* loss, float* conf,
-                     int64_t* pred, void* grad_logits, int grad_dtype, float grad_scale, float* loss_mean,
+                     int64_t* pred, void* grad_logits, long ldg, int grad_dtype, float grad_scale, float* loss_mean,
                      unsigned int* ticket, hipStream_t st) {
   VQAF_REQUIRE(logits != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE((loss == nullptr && grad_logits == nullptr) || targets != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype) && (grad_logits == nullptr || vqaf_dtype_ok(grad_dtype)), VQAF_E_DTYPE);
-  VQAF_REQUIRE(B > 0 && C > 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(B > 0 && C > 0 && (grad_logits == nullptr || ldg >= C), VQAF_E_SHAPE);
   const int rows_per_block = DP_THREADS / 64;
   const dim3 grid((B + rows_per_block - 1) / rows_per_block), block(DP_THREADS);
-#define VQAF_CE(LB, GB) hipLaunchKernelGGL((ce_conf_kernel<LB, GB>), grid, block, 0, st, logits, targets, B, C, loss, conf, pred, grad_logits, grad_scale, loss_mean, ticket)
+#define VQAF_CE(LB, GB) hipLaunchKernelGGL((ce_conf_kernel<LB, GB>), grid, block, 0, st, logits, targets, B, C, loss, conf, pred, grad_logits, ldg, grad_scale, loss_mean, ticket)
   const bool gb = grad_logits != nullptr && grad_dtype == VQAF_BF16;
   if (dtype == VQAF_BF16) { if (gb) VQAF_CE(true, true); else VQAF_CE(true, false); }
   else { if (gb) VQAF_CE(false, true); else VQAF_CE(false, false); }
@@ -1353,16 +1354,16 @@ extern "C" int vqaf_ce_conf(const void* logits, const int64_t* targets, int B, i
                             float* loss, float* conf, int64_t* pred, void* grad_logits, int grad_dtype,
                             float grad_scale, vqaf_stream_t stream) {
   VQAF_ENTRY();
-  return ce_launch(logits, targets, B, C, dtype, loss, conf, pred, grad_logits, grad_dtype, grad_scale, nullptr,
+  return ce_launch(logits, targets, B, C, dtype, loss, conf, pred, grad_logits, C, grad_dtype, grad_scale, nullptr,
                    nullptr, (hipStream_t)stream);
 }
 
 extern "C" int vqaf_ce_mean(const void* logits, const int64_t* targets, int B, int C, int dtype, float* loss,
-                            void* grad_logits, int grad_dtype, float grad_scale, float* loss_mean,
+                            void* grad_logits, long ld_grad, int grad_dtype, float grad_scale, float* loss_mean,
                             unsigned int* ticket, vqaf_stream_t stream) {
   VQAF_ENTRY();
   VQAF_REQUIRE(loss != nullptr && loss_mean != nullptr && ticket != nullptr && targets != nullptr, VQAF_E_NULL);
-  return ce_launch(logits, targets, B, C, dtype, loss, nullptr, nullptr, grad_logits, grad_dtype, grad_scale,
+  return ce_launch(logits, targets, B, C, dtype, loss, nullptr, nullptr, grad_logits, ld_grad, grad_dtype, grad_scale,
                    loss_mean, ticket, (hipStream_t)stream);
 }
 

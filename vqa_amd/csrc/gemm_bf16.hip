@@ -448,14 +448,17 @@ int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
 extern "C" int vqaf_gemm_bf16_supported(long lda, int a_kmajor, long ldb, int b_kmajor, int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0) return 0;
   if (lda % 8 != 0 || ldb % 8 != 0) return 0;                       // 16-byte chunks, 16-byte aligned rows
-  if (a_kmajor ? ((M + 7) / 8 * 8 > lda) : (K % 8 != 0 || K > lda)) return 0;
-  if (b_kmajor ? ((N + 7) / 8 * 8 > ldb) : (K % 8 != 0 || K > ldb)) return 0;
+  // a k-contiguous operand is fetched in 16-byte chunks of 8 k: its rows must hold K rounded up to 8
+  // elements (the caller keeps the elements past K zero; the other operand's rows past K come from zeros)
+  if (a_kmajor ? ((M + 7) / 8 * 8 > lda) : ((K + 7) / 8 * 8 > lda)) return 0;
+  if (b_kmajor ? ((N + 7) / 8 * 8 > ldb) : ((K + 7) / 8 * 8 > ldb)) return 0;
+  if (!a_kmajor && !b_kmajor && K % 8 != 0) return 0;  // then neither operand's tail is known to be zero
   return 1;
 }
 
 namespace {
-// tile plan of one product; false when it would want the contraction split (few tiles)
-bool plan_wgrad(GemmArgs& g, int& MT, int M, int N, int K) {
+// tile plan of one product; returns its tile count
+long plan_wgrad(GemmArgs& g, int& MT, int M, int N, int K) {
   MT = (M > 4096 || K > 2048) ? 2 : 1;  // short contractions: 64 x 64 tiles, three workgroups per CU
   const int BM = 64 * MT;
   g.tiles_m = (M + BM - 1) / BM;
@@ -470,7 +473,7 @@ bool plan_wgrad(GemmArgs& g, int& MT, int M, int N, int K) {
   }
   g.M = M; g.N = N; g.K = K;
   g.k_per_split = (K + GB_BK - 1) / GB_BK * GB_BK;
-  return (long)g.tiles_m * g.tiles_n >= 192;
+  return (long)g.tiles_m * g.tiles_n;
 }
 }  // namespace
 
@@ -487,6 +490,7 @@ extern "C" int vqaf_gemm_bf16_wgrad_group(int n, const void* const* A, const lon
   GemmGroup G;
   G.n = n;
   int mt_all = 0, next = 0;
+  long total_tiles = 0;
   for (int i = 0; i < n; ++i) {
     VQAF_REQUIRE(A[i] && B[i] && C[i], VQAF_E_NULL);
     VQAF_REQUIRE(M[i] > 0 && N[i] > 0 && ldc[i] >= N[i], VQAF_E_SHAPE);
@@ -494,9 +498,8 @@ extern "C" int vqaf_gemm_bf16_wgrad_group(int n, const void* const* A, const lon
     VQAF_REQUIRE(vqaf_aligned16(A[i]) && vqaf_aligned16(B[i]), VQAF_E_ALIGN);
     GemmArgs& g = G.p[i];
     int MT = 1;
-    // a product with too few tiles wants its contraction split, and products of different tile heights
-    // need different kernels: the caller launches those one by one
-    VQAF_REQUIRE(plan_wgrad(g, MT, M[i], N[i], K), VQAF_E_SHAPE);
+    // products of different tile heights need different kernels: the caller launches those one by one
+    total_tiles += plan_wgrad(g, MT, M[i], N[i], K);
     VQAF_REQUIRE(i == 0 || MT == mt_all, VQAF_E_SHAPE);
     mt_all = MT;
     g.A = reinterpret_cast<const bf16_t*>(A[i]);
@@ -511,6 +514,8 @@ extern "C" int vqaf_gemm_bf16_wgrad_group(int n, const void* const* A, const lon
     G.first[i] = next;
     next += g.tiles_m * g.tiles_n;
   }
+  // a launch with too few tiles altogether wants its contractions split: left to the single-product entry
+  VQAF_REQUIRE(total_tiles >= 192, VQAF_E_SHAPE);
   for (int i = n; i <= GB_MAX_GROUP; ++i) G.first[i] = next;
   for (int i = n; i < GB_MAX_GROUP; ++i) G.p[i] = G.p[0];
   hipStream_t st = (hipStream_t)stream;

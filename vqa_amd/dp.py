@@ -131,14 +131,15 @@ class _GhostLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         (w,) = ctx.saved_tensors
-        gy = gy.contiguous()
+        if ops.zero_padded_pitch(gy) is None:  # (a zero-padded backprop of the loss is used where it lies)
+            gy = gy.contiguous()
         ctx.tape.g = gy
         if not ctx.needs_input_grad[0]:
             return None, None, None, None
         Bn, Out = gy.shape
         In = w.shape[1]
         if gy.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.is_contiguous() and \
-                ops.gemm_bf16_supported(Out, False, In, True, Bn, In, Out):
+                ops.gemm_bf16_supported(gy.stride(0), False, In, True, Bn, In, Out):
             gx = torch.empty(Bn, In, dtype=torch.bfloat16, device=gy.device)
             ops.gemm_bf16(gy, False, w, True, Bn, In, Out, gx)
         else:
@@ -515,7 +516,8 @@ class DPOptimizer:
         B = tapes[0].g.shape[0]
         st = stream_ptr(dev)
         for t in tapes:
-            a, g = t.a.contiguous(), t.g.contiguous()
+            a = t.a.contiguous()
+            g = t.g if ops.zero_padded_pitch(t.g) is not None else t.g.contiguous()
             t.a = a if a.dtype == g.dtype else a.to(g.dtype)
             t.g = g
         # a mean-reduced loss hands back gradients divided by B; undo it (Opacus: loss_reduction)
@@ -535,9 +537,10 @@ class DPOptimizer:
         if n <= 8 and same_dtype:
             import ctypes
             pa = (ctypes.c_void_p * n)(*[ptr(t.a) for t in tapes])
-            pg = (ctypes.c_void_p * n)(*[ptr(t.g) for t in tapes])
+            # a zero-padded backprop enters with its padded width (the zeros change neither norm nor scaling)
+            pg = (ctypes.c_void_p * n)(*[t.g.data_ptr() for t in tapes])
             din = (ctypes.c_int * n)(*[t.a.shape[1] for t in tapes])
-            dout = (ctypes.c_int * n)(*[t.g.shape[1] for t in tapes])
+            dout = (ctypes.c_int * n)(*[t.g.stride(0) for t in tapes])
             kind = (ctypes.c_int * n)(*[2 if t.kind != "linear" else int(t.module.bias is not None)
                                         for t in tapes])
             # the same launch scales every recorded backprop row by its clip coefficient in place
@@ -549,6 +552,7 @@ class DPOptimizer:
         else:
             sq = torch.empty(B, dtype=torch.float32, device=dev)
             for i, t in enumerate(tapes):
+                t.g = t.g.contiguous()  # (a zero-padded backprop is only used in place by the one-launch path)
                 a, g = t.a, t.g
                 if t.kind == "linear":
                     check(lib.vqaf_ghost_sqnorm_linear(ptr(a), ptr(g), B, a.shape[1], g.shape[1],
@@ -569,7 +573,7 @@ class DPOptimizer:
                 zero += [self._slice(S, m.weight), self._slice(S, m.bias)]
             elif t.g.dtype == torch.bfloat16 and not (
                     prescaled and t.a.dtype == torch.bfloat16 and
-                    ops.gemm_bf16_supported(t.g.shape[1], True, t.a.shape[1], True, t.g.shape[1], t.a.shape[1], B)):
+                    ops.gemm_bf16_supported(t.g.stride(0), True, t.a.shape[1], True, t.g.shape[1], t.a.shape[1], B)):
                 zero += [self._slice(S, m.weight)] + ([self._slice(S, m.bias)] if m.bias is not None else [])
         pre_zeroed = 0 < len(zero) <= 8
         if pre_zeroed:
@@ -582,8 +586,8 @@ class DPOptimizer:
         grouped = []
         if prescaled:
             cand = [t for t in tapes if t.kind == "linear" and t.g.dtype == torch.bfloat16 and
-                    t.a.dtype == torch.bfloat16 and t.g.is_contiguous() and
-                    ops.gemm_bf16_supported(t.g.shape[1], True, t.a.shape[1], True, t.g.shape[1], t.a.shape[1], B)]
+                    t.a.dtype == torch.bfloat16 and t.g.stride(1) == 1 and
+                    ops.gemm_bf16_supported(t.g.stride(0), True, t.a.shape[1], True, t.g.shape[1], t.a.shape[1], B)]
             if 2 <= len(cand) <= 4:
                 items = [(t.g, t.a, self._slice(S, t.module.weight).view(t.g.shape[1], t.a.shape[1]),
                           self._slice(S, t.module.bias) if t.module.bias is not None else None) for t in cand]
@@ -606,7 +610,7 @@ class DPOptimizer:
         for t in tapes:
             if any(t is c for c in grouped):
                 continue
-            a, g = t.a, t.g.contiguous()
+            a, g = t.a, (t.g if ops.zero_padded_pitch(t.g) is not None else t.g.contiguous())
             m = t.module
             if t.kind == "linear":
                 sw = self._slice(S, m.weight)
@@ -614,10 +618,11 @@ class DPOptimizer:
                 probe = f"clipped_sum_linear:{g.shape[1]}x{a.shape[1]}"
                 In_, Out_ = a.shape[1], g.shape[1]
                 if prescaled and g.dtype == torch.bfloat16 and a.dtype == torch.bfloat16 and \
-                        ops.gemm_bf16_supported(Out_, True, In_, True, Out_, In_, B):
+                        ops.gemm_bf16_supported(g.stride(0), True, In_, True, Out_, In_, B):
                     # S = G^T A with the batch as the contraction index; Sb = column sums of G
                     ops.gemm_bf16(g, True, a, True, Out_, In_, B, sw.view(Out_, In_), colsum=sb, name=probe)
                 else:
+                    g = g.contiguous()
                     ops._probe(probe, "begin")
                     check(lib.vqaf_clipped_sum_linear(ptr(a), ptr(g), None if prescaled else ptr(coef), B,
                                                       In_, Out_, dtype_code(g),

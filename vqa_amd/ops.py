@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -702,6 +704,20 @@ def ce_conf(logits: torch.Tensor, targets: Optional[torch.Tensor] = None, want_l
 
 
 _ce_tickets: dict = {}
+_zero_padded: dict = {}  # id(buffer) -> weak reference: (B, ld) buffers whose columns past the logical width are zero
+
+
+def zero_padded_pitch(t: torch.Tensor) -> Optional[int]:
+    """Row pitch of `t` if it is the leading-columns view of one of the zero-padded gradient buffers the
+    mean cross-entropy hands out (the library's bf16 GEMMs may then read whole 16-byte chunks past its
+    logical width), else None."""
+    base = t._base
+    if base is None or t.dim() != 2 or t.stride(1) != 1 or t.storage_offset() != 0:
+        return None
+    ref = _zero_padded.get(id(base))
+    if ref is None or ref() is not base or t.stride(0) != base.shape[1] or t.shape[0] != base.shape[0]:
+        return None
+    return int(t.stride(0))
 
 
 class _MeanCE(torch.autograd.Function):
@@ -717,7 +733,13 @@ class _MeanCE(torch.autograd.Function):
         dev = lg.device
         C = lg.shape[1]
         loss = torch.empty(B, dtype=torch.float32, device=dev)
-        grad = torch.empty(B, C, dtype=gdt, device=dev)
+        # bf16 gradient rows are padded with zeros to a multiple of 8 elements (16 bytes): a 430-class head's
+        # backprop is then a legal operand of the library's own bf16 GEMMs (input gradient, clipped sum)
+        ldg = (C + 7) // 8 * 8 if gdt == torch.bfloat16 else C
+        buf = torch.empty(B, ldg, dtype=gdt, device=dev)
+        if ldg != C:
+            _zero_padded[id(buf)] = weakref.ref(buf, lambda _r, k=id(buf): _zero_padded.pop(k, None))
+        grad = buf[:, :C]
         mean = torch.empty((), dtype=torch.float32, device=dev)
         # one self-resetting ticket word per device, made before any graph capture can be under way (a
         # tensor allocated during a capture would live in that graph's memory pool); mean losses computed
@@ -728,8 +750,9 @@ class _MeanCE(torch.autograd.Function):
                 raise RuntimeError("cross_entropy_mean: run one step eagerly before capturing a HIP graph")
             ticket = _ce_tickets[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
         check(load().vqaf_ce_mean(ptr(lg), ptr(targets.to(torch.int64).contiguous()), B, C, dtype_code(lg), ptr(loss),
-                                  ptr(grad), dtype_code(grad), 1.0 / B, ptr(mean), ptr(ticket), stream_ptr(dev)),
+                                  ptr(buf), ldg, dtype_code(buf), 1.0 / B, ptr(mean), ptr(ticket), stream_ptr(dev)),
               "vqaf_ce_mean")
+        ctx.buf = buf  # the unit-gradient backward hands on a view of it (its base stays this object)
         ctx.save_for_backward(grad)
         ctx.in_dtype = logits.dtype
         # kept for the rare backward with a non-unit incoming gradient (see backward); no copy is made
@@ -740,7 +763,8 @@ class _MeanCE(torch.autograd.Function):
     def backward(ctx, grad_out):
         (grad,) = ctx.saved_tensors
         if grad_out is _unit_grads.get((grad_out.device, grad_out.dtype)) and grad.dtype == ctx.in_dtype:
-            return grad, None  # loss.backward(gradient=unit_gradient(loss)): the factor is exactly 1
+            # loss.backward(gradient=unit_gradient(loss)): the factor is exactly 1
+            return ctx.buf[:, :grad.shape[1]], None
         if grad.dtype == torch.float32 and ctx.in_dtype in (torch.float32, torch.bfloat16) and grad_out.numel() == 1:
             # one launch: the product is rounded straight into the logits' dtype
             out = torch.empty(grad.shape, dtype=ctx.in_dtype, device=grad.device)
