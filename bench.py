@@ -9,12 +9,12 @@ zero_grad -> CoAttention(pruning, keep 0.5, adversarial mixing) forward -> class
 mean CE -> backward (classifier input gradients, fusion input gradients) -> per-sample norms,
 clip (C = 1.0), clipped sums, Gaussian noise (sigma = 1.0), RCCL all-reduce, AdamW step.
 
-The workload is BASELINE.json configs[2], batch 1024, on every GPU: N ranks process N such batches
-per step (logical batch 1024*N, `--scaling weak`, the default: per-GPU work is fixed as N grows, and
-the only exchange is the all-reduce of the classifier's noisy gradient sum).  An N > 1 run also
-measures the strong-scaling variant (logical batch 1024 sharded 1024/N per GPU, where the step is
-bound by its launch count) and reports it under "strong_scaling_1024"; `--scaling strong` swaps the
-two.  At N = 1 the two are the same run.
+The workload is BASELINE.json configs[2]: logical batch 1024, sharded 1024/N per GPU (`--scaling
+strong`, the default, because that is what the config names; at N = 1 the whole batch sits on one
+GPU).  An N > 1 run also measures the weak-scaling variant (1024 per GPU, logical batch 1024*N: per-GPU
+work fixed, the only exchange is the all-reduce of the classifier's noisy gradient sum) and reports it
+under "weak_scaling_1024_per_gpu"; `--scaling weak` swaps the two.  At 128 samples per GPU the step is
+bound by its launch count, so the strong-scaling figure flattens by construction.
 
 Launch path: the step is captured into HIP graphs (one per rotating input set).  With several
 ranks the collective stays outside the graphs: graph(local work) -> eager RCCL all-reduce ->
@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=LOGICAL_BATCH,
                     help="logical whole-job batch (strong scaling) or per-GPU batch (weak scaling)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
