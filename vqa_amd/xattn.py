@@ -119,12 +119,18 @@ class _DenseSingleQuery(torch.autograd.Function):
             q_c = q_c.float()
         f32 = dict(dtype=torch.float32, device=dev)
         qp = torch.empty(B, E, **f32)
-        # qp = query Wq^T + bq
-        _gemm((q_c, 0), (0, E, 1), (w_in_c, 0), (0, 1, E), (qp, 0), (0, E), 1, B, E, E, bias=(b_in_c, 0))
-        # u[:,h,:] = qp[:, head h] Wk[head h, :] / sqrt(dh)
         u = torch.empty(B, H, E, **f32)
-        _gemm((qp, 0), (dh, E, 1), (w_in_c, E * E), (dh * E, E, 1), (u, 0), (E, H * E), H, B, E, dh,
-              alpha=1.0 / math.sqrt(dh))
+        if q_c.dtype == torch.bfloat16 and w_in_c.dtype == torch.bfloat16 and b_in_c.dtype == torch.bfloat16 \
+                and E == 512 and dh == 64:
+            # both products in one launch on the bf16 matrix cores (f32-accurate: see vqaf_fold_query)
+            check(load().vqaf_fold_query(ptr(q_c), ptr(w_in_c), ptr(b_in_c), B, E, H, _lib.BF16, _lib.BF16, ptr(qp),
+                                         ptr(u), stream_ptr(dev)), "vqaf_fold_query")
+        else:
+            # qp = query Wq^T + bq
+            _gemm((q_c, 0), (0, E, 1), (w_in_c, 0), (0, 1, E), (qp, 0), (0, E), 1, B, E, E, bias=(b_in_c, 0))
+            # u[:,h,:] = qp[:, head h] Wk[head h, :] / sqrt(dh)
+            _gemm((qp, 0), (dh, E, 1), (w_in_c, E * E), (dh * E, E, 1), (u, 0), (E, H * E), H, B, E, dh,
+                  alpha=1.0 / math.sqrt(dh))
         z, p = _tokens_forward(seq_c, u)
         # attn[:, head h] = z[:,h,:] Wv[head h, :]^T + bv[head h]
         attn = torch.empty(B, E, **f32)
