@@ -82,10 +82,115 @@ struct GhostLayers {
   int kind[GC_MAX_LAYERS];  // 0 Linear without bias, 1 Linear with bias, 2 affine
   int n;
 };
-// The layers' partial sums stay in registers until ONE block reduction at the end (no barrier between
-// layers, so the rows of different layers are in flight together), and the in-place scaling moves 16
-// bytes per lane where the row pitch allows it.  Few registers on purpose: eight workgroups share a
-// compute unit and cover each other's memory latency.
+// Shared tail of the two ghost_clip kernels: one block reduction for all layers, the clip coefficient.
+__device__ __forceinline__ float ghost_clip_coef(const GhostLayers& L, const float (&part)[2 * GC_MAX_LAYERS],
+                                                 float (*red)[2 * GC_MAX_LAYERS], float* s_coef, int b, float max_norm,
+                                                 float scale, float* coef, float* norms, float* sq_out) {
+  constexpr int NW = DP_THREADS / 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int j = 0; j < 2 * GC_MAX_LAYERS; ++j) {
+    if (j < 2 * L.n) {
+      const float w = wave_sum(part[j]);
+      if (lane == 0) red[wave][j] = w;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float total = 0.f;
+    for (int l = 0; l < L.n; ++l) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int w = 0; w < NW; ++w) {
+        s0 += red[w][2 * l];
+        s1 += red[w][2 * l + 1];
+      }
+      total += L.kind[l] == 2 ? s0 : s0 * s1 + (L.kind[l] == 1 ? s1 : 0.f);
+    }
+    const float n = scale * sqrtf(total);
+    const float c = scale * fminf(1.0f, max_norm / (n + 1e-6f));
+    coef[b] = c;
+    *s_coef = c;
+    if (norms != nullptr) norms[b] = n;
+    if (sq_out != nullptr) sq_out[b] = total;
+  }
+  __syncthreads();
+  return *s_coef;
+}
+
+__device__ __forceinline__ float sumsq_bf16x8(u32x4 r) {
+  float s = 0.f;
+  s = fmaf(bf16_lo(r.x), bf16_lo(r.x), s); s = fmaf(bf16_hi(r.x), bf16_hi(r.x), s);
+  s = fmaf(bf16_lo(r.y), bf16_lo(r.y), s); s = fmaf(bf16_hi(r.y), bf16_hi(r.y), s);
+  s = fmaf(bf16_lo(r.z), bf16_lo(r.z), s); s = fmaf(bf16_hi(r.z), bf16_hi(r.z), s);
+  s = fmaf(bf16_lo(r.w), bf16_lo(r.w), s); s = fmaf(bf16_hi(r.w), bf16_hi(r.w), s);
+  return s;
+}
+__device__ __forceinline__ float affine_term_bf16x2(unsigned int x, unsigned int g, float s) {
+  const float g0 = bf16_lo(g), g1 = bf16_hi(g), p0 = bf16_lo(x) * g0, p1 = bf16_hi(x) * g1;
+  s = fmaf(p0, p0, s); s = fmaf(g0, g0, s);
+  s = fmaf(p1, p1, s); s = fmaf(g1, g1, s);
+  return s;
+}
+__device__ __forceinline__ unsigned int scale_bf16x2(unsigned int w, float c) {
+  return pack_bf16x2(c * bf16_lo(w), c * bf16_hi(w));
+}
+
+// bf16 tapes whose rows are 16-byte aligned and at most 2048 elements wide (the host checks): EVERY row of
+// the sample is requested before anything is summed -- a thread holds its eight elements of each row as
+// four raw registers, 64 for eight layers -- so the workgroup pays one memory latency instead of one per
+// layer, and the in-place scaling g <- c g reuses the registers instead of reading the rows again.
+__global__ void __launch_bounds__(DP_THREADS, 4)
+ghost_clip_rows_kernel(GhostLayers L, float max_norm, float scale, int scale_g, float* __restrict__ coef,
+                       float* __restrict__ norms, float* __restrict__ sq_out) {
+  __shared__ float red[DP_THREADS / 64][2 * GC_MAX_LAYERS];
+  __shared__ float s_coef;
+  const int b = blockIdx.x, i0 = threadIdx.x * 8;
+  u32x4 ra[GC_MAX_LAYERS], rg[GC_MAX_LAYERS];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int l = 0; l < GC_MAX_LAYERS; ++l) {
+    ra[l] = zero4;
+    rg[l] = zero4;
+    if (l < L.n) {
+      const int Out = L.out_dim[l], In = L.kind[l] == 2 ? Out : L.in_dim[l];
+      if (i0 < In) ra[l] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(L.a[l]) + (size_t)b * In + i0);
+      if (i0 < Out) rg[l] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(L.g[l]) + (size_t)b * Out + i0);
+    }
+  }
+  float part[2 * GC_MAX_LAYERS];
+#pragma unroll
+  for (int l = 0; l < GC_MAX_LAYERS; ++l) {
+    float s0 = 0.f, s1 = 0.f;
+    if (l < L.n) {
+      if (L.kind[l] == 2) {
+        s0 = affine_term_bf16x2(ra[l].x, rg[l].x, s0);
+        s0 = affine_term_bf16x2(ra[l].y, rg[l].y, s0);
+        s0 = affine_term_bf16x2(ra[l].z, rg[l].z, s0);
+        s0 = affine_term_bf16x2(ra[l].w, rg[l].w, s0);
+      } else {
+        s0 = sumsq_bf16x8(ra[l]);
+        s1 = sumsq_bf16x8(rg[l]);
+      }
+    }
+    part[2 * l] = s0;
+    part[2 * l + 1] = s1;
+  }
+  const float c = ghost_clip_coef(L, part, red, &s_coef, b, max_norm, scale, coef, norms, sq_out);
+  if (!scale_g) return;
+#pragma unroll
+  for (int l = 0; l < GC_MAX_LAYERS; ++l) {
+    if (l < L.n && i0 < L.out_dim[l]) {
+      u32x4 v;
+      v.x = scale_bf16x2(rg[l].x, c); v.y = scale_bf16x2(rg[l].y, c);
+      v.z = scale_bf16x2(rg[l].z, c); v.w = scale_bf16x2(rg[l].w, c);
+      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(const_cast<void*>(L.g[l])) + (size_t)b * L.out_dim[l] + i0) = v;
+    }
+  }
+}
+
+// The general form (f32 tapes, unaligned or wider rows): the layers' partial sums stay in registers until
+// ONE block reduction at the end (no barrier between layers), and the in-place scaling moves 16 bytes per
+// lane where the row pitch allows it.
 template <bool BF16>
 __global__ void __launch_bounds__(DP_THREADS)
 ghost_clip_kernel(GhostLayers L, float max_norm, float scale, int scale_g, float* __restrict__ coef,
@@ -156,37 +261,10 @@ ghost_clip_kernel(GhostLayers L, float max_norm, float scale, int scale_g, float
     part[2 * l] = s0;
     part[2 * l + 1] = s1;
   }
-  const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-  for (int j = 0; j < 2 * GC_MAX_LAYERS; ++j) {
-    if (j < 2 * L.n) {
-      const float w = wave_sum(part[j]);
-      if (lane == 0) red[wave][j] = w;
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float total = 0.f;
-    for (int l = 0; l < L.n; ++l) {
-      float s0 = 0.f, s1 = 0.f;
-      for (int w = 0; w < NW; ++w) {
-        s0 += red[w][2 * l];
-        s1 += red[w][2 * l + 1];
-      }
-      total += L.kind[l] == 2 ? s0 : s0 * s1 + (L.kind[l] == 1 ? s1 : 0.f);
-    }
-    const float n = scale * sqrtf(total);
-    const float c = scale * fminf(1.0f, max_norm / (n + 1e-6f));
-    coef[b] = c;
-    s_coef = c;
-    if (norms != nullptr) norms[b] = n;
-    if (sq_out != nullptr) sq_out[b] = total;
-  }
+  const float c = ghost_clip_coef(L, part, red, &s_coef, b, max_norm, scale, coef, norms, sq_out);
   if (!scale_g) return;
   // g_b <- coef_b * g_b for every layer, in place (the rows were just read, so they are cache hot):
   // the clipped-sum kernels then run with coef == NULL, as plain batch contractions.
-  __syncthreads();
-  const float c = s_coef;
   for (int l = 0; l < L.n; ++l) {
     const int Out = L.out_dim[l];
     void* gl = const_cast<void*>(L.g[l]);
@@ -1091,7 +1169,17 @@ extern "C" int vqaf_ghost_clip(int n_layers, const void* const* a_host, const vo
     L.out_dim[l] = out_dim_host[l];
     L.kind[l] = kind_host[l];
   }
-  if (dtype == VQAF_BF16)
+  // bf16 rows that are 16-byte aligned and fit one 8-element piece per thread: the register-resident form
+  bool rows_fit = dtype == VQAF_BF16;
+  for (int l = 0; l < n_layers && rows_fit; ++l) {
+    const int in = kind_host[l] == 2 ? out_dim_host[l] : in_dim_host[l], out = out_dim_host[l];
+    rows_fit = in % 8 == 0 && out % 8 == 0 && in <= DP_THREADS * 8 && out <= DP_THREADS * 8 &&
+               vqaf_aligned16(a_host[l]) && vqaf_aligned16(g_host[l]);
+  }
+  if (rows_fit)
+    hipLaunchKernelGGL(ghost_clip_rows_kernel, dim3(B), dim3(DP_THREADS), 0, (hipStream_t)stream, L,
+                       max_norm, scale, scale_g_inplace, coef, norms, sq);
+  else if (dtype == VQAF_BF16)
     hipLaunchKernelGGL(ghost_clip_kernel<true>, dim3(B), dim3(DP_THREADS), 0, (hipStream_t)stream, L,
                        max_norm, scale, scale_g_inplace, coef, norms, sq);
   else
