@@ -402,6 +402,22 @@ int vqaf_gemm_bf16(const void* A, long lda, int a_kmajor, const void* B, long ld
                    int K, const void* bias, int bias_dtype, void* C, long ldc, int c_dtype, int accumulate,
                    float* colsum, vqaf_stream_t stream);
 
+/* Linear -> GroupNorm (-> ReLU -> Dropout) of the DP classifier (model/model.py:55-58 after
+ * ModuleValidator.fix, train.py:124) in ONE launch: the normalisation runs on the Linear's output tile
+ * before it leaves the workgroup.  x (B,K) bf16 rows ldx apart, W (C,K) bf16 rows ldw apart, bias (C) or
+ * NULL; gamma, beta (C) `param_dtype`; outputs as vqaf_groupnorm_fwd writes them: y (B,C) bf16 (the
+ * activation), xhat (B,C) bf16, rstd (B,groups) f32; the dropout arguments have that call's meaning.  The
+ * Linear output is rounded to bf16 before it is normalised and every sum is taken in vqaf_groupnorm_fwd's
+ * order, so the results equal vqaf_gemm_bf16 followed by vqaf_groupnorm_fwd bit for bit.  Covered
+ * (vqaf_linear_groupnorm_supported): C a multiple of 64, group size 8, 16, 32 or 64, and the operand rules
+ * of vqaf_gemm_bf16 for two k-contiguous operands; otherwise VQAF_E_ALIGN (use the two calls). */
+int vqaf_linear_groupnorm_supported(long ldx, long ldw, int B, int C, int K, int groups);
+int vqaf_linear_groupnorm_fwd(const void* x, long ldx, const void* W, long ldw, const void* bias,
+                              int bias_dtype, int B, int C, int K, const void* gamma, const void* beta,
+                              int param_dtype, int groups, float eps, int relu, float dropout_p,
+                              uint64_t dropout_seed, const uint64_t* dropout_counter, void* y, void* xhat,
+                              float* rstd, vqaf_stream_t stream);
+
 /* n <= 4 products of the clipped-sum shape in ONE launch: C_i (M_i,N_i) f32 = A_i^T B_i with A_i (K,M_i) and
  * B_i (K,N_i) bf16, both k-major, the same K (the batch); colsum (array of n pointers, or NULL, entries may be
  * NULL) receives the column sums of A_i; accumulate != 0 adds into C_i / colsum_i.  The clipped sums of the

@@ -754,3 +754,31 @@ def test_mean_ce_value_in_one_launch(dev):
         lb = lg.bfloat16()
         wb = float(fo.per_sample_ce(lb.float(), y).double().mean())
         assert abs(float(ops.cross_entropy_mean(lb.to(dev), y.to(dev))) - wb) <= 2e-6 * max(1.0, abs(wb))
+
+
+def test_linear_groupnorm_in_one_launch_equals_the_two_launches(dev):
+    """GroupNorm (+ReLU +Dropout) as the epilogue of the Linear's GEMM: outputs, saved statistics, every
+    tape and the input gradient equal the separate launches bit for bit, for whole and ragged row tiles,
+    group sizes 64 and 32 (the classifier's) and 8, with and without dropout."""
+    from vqa_amd import dp
+    for B, In, C, groups, p in ((256, 1024, 2048, 32, 0.3), (100, 2048, 1024, 32, 0.3), (37, 128, 64, 8, 0.0),
+                                (64, 64, 128, 8, 0.5)):
+        outs = []
+        for fuse in (False, True):
+            torch.manual_seed(5)
+            m = nn.Sequential(nn.Linear(In, C), nn.GroupNorm(groups, C), nn.ReLU(), nn.Dropout(p), nn.Linear(C, 10)).to(dev)
+            gsm = dp.GradSampleModule(m)
+            gsm.fuse_linear_groupnorm = fuse
+            gsm.train()
+            x = gi.normal(3, B, In).to(dev).bfloat16().requires_grad_()
+            torch.manual_seed(11)  # the dropout stream is seeded from torch's global seed on first use
+            y = gsm(x)
+            y.float().square().sum().backward()
+            tapes = [(t.a.clone(), t.g.clone()) for t in gsm.tapes]
+            outs.append((y.detach().clone(), x.grad.clone(), tapes, len(gsm.tapes)))
+        (y0, gx0, t0, n0), (y1, gx1, t1, n1) = outs
+        assert n0 == n1 == 3
+        assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+        assert float(y0.float().abs().sum()) > 0
+        for (a0, g0), (a1, g1) in zip(t0, t1):
+            assert torch.equal(a0, a1) and torch.equal(g0, g1)

@@ -50,6 +50,21 @@ struct GemmArgs {
   int tiles_m, tiles_n, reg_m, reg_n;  // output tiles; XCD regions (reg_m * reg_n == 8) or 0
 };
 
+// GroupNorm (+ReLU +inverted dropout) applied to the output tile of a Linear before it leaves the
+// workgroup (model/model.py:55-58: Linear -> GroupNorm -> ReLU -> Dropout).  64-column tiles hold whole
+// groups of 8..64 channels, so the statistics of a (sample, group) never leave the tile.
+struct GnEpi {
+  const void* gamma;             // (N) bf16 or f32
+  const void* beta;
+  void* y;                       // (M,N) bf16: the activation handed to the next layer
+  void* xhat;                    // (M,N) bf16: normalised input, kept for the backward and the ghost norm
+  float* rstd;                   // (M, groups)
+  const uint64_t* drop_counter;  // {unused, counter} or NULL
+  unsigned long long drop_seed;
+  float eps, drop_p;
+  int groups, relu, param_bf16;
+};
+
 __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -91,8 +106,9 @@ __device__ __forceinline__ int kswz(int k) {
 // fall on 16 distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int rswz(int r) { return (r >> 1) & 7; }
 
-template <int MT, bool A_KMAJOR, bool B_KMAJOR, bool COLSUM, int STAGES = GB_STAGES>
-__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile_m, const int tile_n) {
+template <int MT, bool A_KMAJOR, bool B_KMAJOR, bool COLSUM, int STAGES = GB_STAGES, int EPI = 0>
+__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile_m, const int tile_n,
+                                               const GnEpi* epi = nullptr) {
   constexpr int BM = 64 * MT;
   constexpr int A_BYTES = BM * GB_BK * 2;
   constexpr int B_BYTES = GB_BN * GB_BK * 2;
@@ -321,6 +337,77 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile
   if (g.bias != nullptr && n < g.N)
     bias_v = g.bias_bf16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(g.bias)[n])
                          : reinterpret_cast<const float*>(g.bias)[n];
+  if constexpr (EPI == 1) {
+    // GroupNorm epilogue (64 x 64 tile, N a multiple of 64, 8 <= group size <= 64 dividing 64).  The tile
+    // goes through LDS (the operand ring is free now; the fetching waves have left) so that a thread owns 8
+    // consecutive channels of a row, as a lane of the stand-alone kernel does: the Linear output is rounded
+    // to bf16 first and every sum is taken in that kernel's order, so both paths give the same bits.
+    static_assert(MT == 1 && !A_KMAJOR && !B_KMAJOR && !COLSUM, "GroupNorm epilogue: forward tiles of 64 x 64");
+    constexpr int TP = 68;  // floats per staged row (16-byte aligned rows)
+    float* T = reinterpret_cast<float*>(gb_lds);
+    const GnEpi& e = *epi;
+    __syncthreads();  // every wave is done with the last k-step's fragments
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      T[row * TP + wn * 32 + (lane & 31)] = bf16_to_f32(f32_to_bf16(acc[0][r] + bias_v));
+    }
+    __syncthreads();
+    const int C = g.N, gs = C / e.groups, lpg = gs / 8;
+    const int chunk = tid & 7, c0 = n0 + 8 * chunk;
+    float ga[8], be[8];
+    if (e.param_bf16) { load8<true>(e.gamma, (size_t)c0, ga); load8<true>(e.beta, (size_t)c0, be); }
+    else { load8<false>(e.gamma, (size_t)c0, ga); load8<false>(e.beta, (size_t)c0, be); }
+    const bool drop = e.drop_counter != nullptr && e.drop_p > 0.f;
+    const unsigned long long dcounter = drop ? e.drop_counter[1] : 0ull;
+    const unsigned int drop_thr = (unsigned int)(e.drop_p * 65536.0f);
+    const float keep_scale = drop ? 1.0f / (1.0f - e.drop_p) : 1.0f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = (tid >> 3) + 32 * pass, m = m0 + row;
+      const int mb = min(m, g.M - 1);  // rows past M repeat the last row (never stored)
+      float v[8];
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * TP + 8 * chunk);
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * TP + 8 * chunk + 4);
+      v[0] = t0[0]; v[1] = t0[1]; v[2] = t0[2]; v[3] = t0[3];
+      v[4] = t1[0]; v[5] = t1[1]; v[6] = t1[2]; v[7] = t1[3];
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sm += v[i];
+      for (int o = lpg >> 1; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+      const float mean = sm / (float)gs;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] -= mean;
+        q = fmaf(v[i], v[i], q);
+      }
+      for (int o = lpg >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      const float rs = rsqrtf(q / (float)gs + e.eps);
+      float yo[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] *= rs;
+        yo[i] = fmaf(v[i], ga[i], be[i]);
+        if (e.relu) yo[i] = fmaxf(yo[i], 0.f);
+      }
+      if (drop) {
+        const Philox4 pr = philox4x32_10(e.drop_seed, ((size_t)mb * C + c0) >> 3, dcounter);
+        const unsigned int w[4] = {pr.x, pr.y, pr.z, pr.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          yo[2 * i] = (w[i] & 0xffffu) >= drop_thr ? yo[2 * i] * keep_scale : 0.f;
+          yo[2 * i + 1] = (w[i] >> 16) >= drop_thr ? yo[2 * i + 1] * keep_scale : 0.f;
+        }
+      }
+      if (m < g.M) {
+        if ((chunk % lpg) == 0) e.rstd[(size_t)m * e.groups + c0 / gs] = rs;
+        store8<true>(e.y, (size_t)m * C + c0, yo);
+        store8<true>(e.xhat, (size_t)m * C + c0, v);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -373,6 +460,14 @@ gemm_bf16_kernel(GemmArgs g) {
   // the extra accumulators between register files at every k-step of every workgroup
   if (g.colsum != nullptr && tile_n == 0) gemm_bf16_body<MT, A_KMAJOR, B_KMAJOR, true, STAGES>(g, tile_m, tile_n);
   else gemm_bf16_body<MT, A_KMAJOR, B_KMAJOR, false, STAGES>(g, tile_m, tile_n);
+}
+
+template <int STAGES>
+__global__ void __launch_bounds__(2 * GB_THREADS)
+gemm_bf16_gn_kernel(GemmArgs g, GnEpi e) {
+  int tile_m, tile_n;
+  tile_of(g, (int)blockIdx.x, tile_m, tile_n);
+  gemm_bf16_body<1, false, false, false, STAGES, 1>(g, tile_m, tile_n, &e);
 }
 
 // Several weight-gradient-shaped products (both operands k-major, the same contraction length) in ONE
@@ -443,7 +538,83 @@ int launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? VQAF_OK : VQAF_E_LAUNCH;
 }
 
+template <int STAGES>
+int launch_gemm_gn(const GemmArgs& g, const GnEpi& e, dim3 grid, hipStream_t st) {
+  constexpr size_t smem = (size_t)STAGES * (64 + GB_BN) * GB_BK * 2;
+  static_assert(smem >= 64 * 68 * sizeof(float), "the staged output tile lives in the operand ring");
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_gn_kernel<STAGES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  hipLaunchKernelGGL((gemm_bf16_gn_kernel<STAGES>), grid, dim3(2 * GB_THREADS), smem, st, g, e);
+  return hipGetLastError() == hipSuccess ? VQAF_OK : VQAF_E_LAUNCH;
+}
+
+// 8 equal regions of the tile grid (one per XCD), as square as the tile counts allow; 0, 0 if none divides
+void pick_regions(int tiles_m, int tiles_n, int BM, int& reg_m, int& reg_n) {
+  reg_m = reg_n = 0;
+  const int cand[4][2] = {{2, 4}, {4, 2}, {1, 8}, {8, 1}};
+  long best = -1;
+  for (const auto& c : cand) {
+    if (tiles_m % c[0] != 0 || tiles_n % c[1] != 0) continue;
+    const long cost = (long)(tiles_m / c[0]) * BM + (long)(tiles_n / c[1]) * GB_BN;
+    if (best < 0 || cost < best) { best = cost; reg_m = c[0]; reg_n = c[1]; }
+  }
+}
+
 }  // namespace
+
+extern "C" int vqaf_linear_groupnorm_supported(long ldx, long ldw, int B, int C, int K, int groups) {
+  if (groups <= 0 || C % groups != 0 || C % 64 != 0) return 0;
+  const int gs = C / groups;
+  if (!(gs == 8 || gs == 16 || gs == 32 || gs == 64)) return 0;
+  return vqaf_gemm_bf16_supported(ldx, 0, ldw, 0, B, C, K);
+}
+
+extern "C" int vqaf_linear_groupnorm_fwd(const void* x, long ldx, const void* W, long ldw, const void* bias,
+                                         int bias_dtype, int B, int C, int K, const void* gamma, const void* beta,
+                                         int param_dtype, int groups, float eps, int relu, float dropout_p,
+                                         uint64_t dropout_seed, const uint64_t* dropout_counter, void* y, void* xhat,
+                                         float* rstd, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(x && W && gamma && beta && y && xhat && rstd, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(param_dtype) && (bias == nullptr || vqaf_dtype_ok(bias_dtype)), VQAF_E_DTYPE);
+  VQAF_REQUIRE(B > 0 && C > 0 && K > 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_linear_groupnorm_supported(ldx, ldw, B, C, K, groups), VQAF_E_ALIGN);
+  VQAF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, VQAF_E_SHAPE);
+  VQAF_REQUIRE(dropout_p == 0.f || (dropout_counter != nullptr && relu), VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_aligned16(x) && vqaf_aligned16(W) && vqaf_aligned16(y) && vqaf_aligned16(xhat) &&
+                   vqaf_aligned16(gamma) && vqaf_aligned16(beta), VQAF_E_ALIGN);
+  const unsigned int* zeros = nullptr;
+  const int rc = zero_block_on_current_device(&zeros);
+  if (rc != VQAF_OK) return rc;
+  GemmArgs g;
+  g.A = reinterpret_cast<const bf16_t*>(x);
+  g.B = reinterpret_cast<const bf16_t*>(W);
+  g.bias = bias;
+  g.C = nullptr;
+  g.colsum = nullptr;
+  g.zeros = zeros;
+  g.lda = ldx; g.ldb = ldw; g.ldc = C;
+  g.M = B; g.N = C; g.K = K;
+  g.k_per_split = (K + GB_BK - 1) / GB_BK * GB_BK;
+  g.tiles_m = (B + 63) / 64; g.tiles_n = C / 64;
+  pick_regions(g.tiles_m, g.tiles_n, 64, g.reg_m, g.reg_n);
+  g.bias_bf16 = bias_dtype == VQAF_BF16 ? 1 : 0;
+  g.out_mode = GB_OUT_BF16;
+  GnEpi e;
+  e.gamma = gamma; e.beta = beta; e.y = y; e.xhat = xhat; e.rstd = rstd;
+  e.drop_counter = dropout_p > 0.f ? dropout_counter : nullptr;
+  e.drop_seed = (unsigned long long)dropout_seed;
+  e.eps = eps; e.drop_p = dropout_p; e.groups = groups; e.relu = relu;
+  e.param_bf16 = param_dtype == VQAF_BF16 ? 1 : 0;
+  const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, 1);
+  // ring depth as the plain forward GEMM picks it: three stages (three workgroups per CU) for 200-512 tiles of 128
+  const long tiles128 = (long)((B + 127) / 128) * (C / 64);
+  if (tiles128 >= 200 && tiles128 <= 512 && K <= 2048 && B <= 4096) return launch_gemm_gn<3>(g, e, grid, (hipStream_t)stream);
+  return launch_gemm_gn<GB_STAGES>(g, e, grid, (hipStream_t)stream);
+}
 
 extern "C" int vqaf_gemm_bf16_supported(long lda, int a_kmajor, long ldb, int b_kmajor, int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0) return 0;

@@ -185,6 +185,61 @@ class _GhostGroupNorm(torch.autograd.Function):
         return gx, None, None, None, None, None, None, None, None, None
 
 
+class _GhostLinearGroupNorm(torch.autograd.Function):
+    """Linear -> GroupNorm (-> ReLU -> Dropout) with the normalisation as the epilogue of the Linear's GEMM
+    (vqaf_linear_groupnorm_fwd: one launch, the same bits as _GhostLinear followed by _GhostGroupNorm).
+    Backward: the GroupNorm backward kernel, then the Linear's input gradient; both layers' tapes are
+    filled as the separate functions fill them."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gn_weight, gn_bias, groups, eps, relu, lin_tape, gn_tape, drop_p=0.0,
+                drop_seed=0, drop_counter=None):
+        w = _as_dtype(weight, x.dtype, lin_tape.shadow)
+        b = None if bias is None else _as_dtype(bias, x.dtype, lin_tape.shadow)
+        ga = _as_dtype(gn_weight.detach(), x.dtype, gn_tape.shadow).contiguous()
+        be = _as_dtype(gn_bias.detach(), x.dtype, gn_tape.shadow).contiguous()
+        Bn, In = x.shape
+        C = w.shape[0]
+        xc = x.contiguous()
+        y = torch.empty(Bn, C, dtype=torch.bfloat16, device=x.device)
+        xhat = torch.empty_like(y)
+        rstd = torch.empty(Bn, groups, dtype=torch.float32, device=x.device)
+        check(load().vqaf_linear_groupnorm_fwd(
+            ptr(xc), In, ptr(w), In, ptr(b), dtype_code(b) if b is not None else 0, Bn, C, In, ptr(ga), ptr(be),
+            dtype_code(ga), groups, float(eps), int(relu), float(drop_p), int(drop_seed) & 0xFFFFFFFFFFFFFFFF,
+            ptr(drop_counter) if drop_p > 0 else None, ptr(y), ptr(xhat), ptr(rstd), stream_ptr(x.device)),
+            "vqaf_linear_groupnorm_fwd")
+        ctx.save_for_backward(w, y, xhat, rstd, ga)
+        ctx.meta = (Bn, C, groups, int(relu), 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0)
+        ctx.tapes = (lin_tape, gn_tape)
+        lin_tape.a = xc.detach()
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        w, y, xhat, rstd, ga = ctx.saved_tensors
+        Bn, C, groups, relu, out_scale = ctx.meta
+        lin_tape, gn_tape = ctx.tapes
+        gy = gy.contiguous().to(y.dtype)
+        g_pre = torch.empty_like(y)
+        gl = torch.empty_like(y)  # gradient at the Linear's output
+        check(load().vqaf_groupnorm_bwd(ptr(gy), ptr(y), ptr(xhat), ptr(rstd), ptr(ga), Bn, C, groups, relu,
+                                        float(out_scale), dtype_code(y), ptr(g_pre), ptr(gl), stream_ptr(y.device)),
+              "vqaf_groupnorm_bwd")
+        gn_tape.a, gn_tape.g = xhat, g_pre
+        lin_tape.g = gl
+        none = (None,) * 12
+        if not ctx.needs_input_grad[0]:
+            return (None,) + none
+        In = w.shape[1]
+        if ops.gemm_bf16_supported(C, False, In, True, Bn, In, C):
+            gx = torch.empty(Bn, In, dtype=torch.bfloat16, device=gy.device)
+            ops.gemm_bf16(gl, False, w, True, Bn, In, C, gx)
+        else:
+            gx = gl.matmul(w)
+        return (gx,) + none
+
+
 class _ScaleGrad(torch.autograd.Function):
     """Identity whose backward multiplies the gradient by a 0-d device tensor (read on the device)."""
 
@@ -224,6 +279,8 @@ class GradSampleModule(nn.Module):
         # this factor, padded / real rows, turns the upstream gradients back into those of the mean over
         # the real rows.  The per-sample gradients of this module are not touched by it.
         self.input_grad_scale = None
+        # Linear followed by GroupNorm (+ReLU +Dropout) as ONE launch where the shapes allow it
+        self.fuse_linear_groupnorm = True
 
     def forward(self, x):
         self.tapes = []
@@ -238,6 +295,23 @@ class GradSampleModule(nn.Module):
             i = 0
             while i < len(children):
                 c = children[i]
+                if self.fuse_linear_groupnorm and isinstance(c, nn.Linear) and i + 1 < len(children) and \
+                        isinstance(children[i + 1], nn.GroupNorm) and x.dim() == 2:
+                    # Linear -> GroupNorm (-> ReLU (-> Dropout)): the normalisation rides on the GEMM's epilogue
+                    gn = children[i + 1]
+                    relu = i + 2 < len(children) and isinstance(children[i + 2], nn.ReLU)
+                    drop = children[i + 3] if relu and i + 3 < len(children) and \
+                        isinstance(children[i + 3], nn.Dropout) else None
+                    p = 0.0
+                    if drop is not None:
+                        if drop.training and drop.p >= 1.0:
+                            drop = None  # p = 1 zeroes everything: leave it to nn.Dropout
+                        else:
+                            p = float(drop.p) if (drop.training and 0.0 < drop.p < 1.0) else 0.0
+                    if self._linear_groupnorm_ok(c, gn, x):
+                        x = self._linear_groupnorm(c, gn, x, relu=relu, drop_p=p)
+                        i += 2 + (1 if relu else 0) + (1 if drop is not None else 0)
+                        continue
                 if isinstance(c, nn.GroupNorm) and i + 1 < len(children) and \
                         isinstance(children[i + 1], nn.ReLU) and x.dim() == 2:
                     # GroupNorm -> ReLU (-> Dropout) in one launch (model/model.py:56-58)
@@ -269,26 +343,47 @@ class GradSampleModule(nn.Module):
             return m(x)  # ReLU, Dropout, Identity ...: parameter-free, plain autograd
         raise ValueError(f"{type(m).__name__} has parameters but no per-sample rule")
 
+    def _linear_groupnorm_ok(self, lin: nn.Linear, gn: nn.GroupNorm, x) -> bool:
+        if x.dtype != torch.bfloat16 or not gn.affine or gn.num_channels != lin.out_features:
+            return False
+        return bool(load().vqaf_linear_groupnorm_supported(lin.in_features, lin.in_features, x.shape[0],
+                                                           lin.out_features, lin.in_features, gn.num_groups))
+
+    def _dropout_stream(self, x, drop_p: float):
+        """(seed, counter tensor) of the next dropout call site.  The mask stream is (seed + call site,
+        step count).  With a DP optimizer attached the count is the one its fused update keeps in device
+        memory (it moves once per step, so no launch is spent on a counter here and a replayed HIP graph
+        draws fresh masks); the call-site index tells apart the dropout layers and repeated forwards of
+        one step.  Without one the module's own counter is used and bumped after each forward."""
+        if drop_p <= 0.0:
+            return 0, None
+        if self.dropout_rng is None or self.dropout_rng.state.device != x.device:
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            # seeded from torch's global seed; ranks that share it still draw different masks
+            self.dropout_rng = ops.PhiloxState(x.device, stream_salt=29 + 1009 * rank)
+        counter = self.step_counter if self.step_counter is not None else self.dropout_rng.state
+        seed = self.dropout_rng.seed + 0x9E3779B97F4A7C15 * (1 + self._drop_calls)
+        self._drop_calls += 1
+        return seed, counter
+
+    def _linear_groupnorm(self, lin: nn.Linear, gn: nn.GroupNorm, x, relu: bool, drop_p: float = 0.0):
+        lin_tape = _Tape(lin, "linear", self.shadow)
+        gn_tape = _Tape(gn, "affine", self.shadow)
+        self.tapes += [lin_tape, gn_tape]
+        seed, counter = self._dropout_stream(x, drop_p)
+        y = _GhostLinearGroupNorm.apply(x, lin.weight, lin.bias, gn.weight, gn.bias, gn.num_groups, gn.eps, relu,
+                                        lin_tape, gn_tape, drop_p, seed, counter)
+        if drop_p > 0.0 and self.step_counter is None:
+            self.dropout_rng.advance()
+        return y
+
     def _groupnorm(self, m: nn.GroupNorm, x, relu: bool, drop_p: float = 0.0):
         if x.dim() != 2 or not m.affine:
             raise ValueError("per-sample rule implemented for affine GroupNorm on (B, C) input")
         tape = _Tape(m, "affine", self.shadow)
         self.tapes.append(tape)
-        seed, counter = 0, None
-        if drop_p > 0.0:
-            if self.dropout_rng is None or self.dropout_rng.state.device != x.device:
-                import torch.distributed as dist
-                rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-                # seeded from torch's global seed; ranks that share it still draw different masks
-                self.dropout_rng = ops.PhiloxState(x.device, stream_salt=29 + 1009 * rank)
-            # The mask stream is (seed + call site, step count).  With a DP optimizer attached the count
-            # is the one its fused update keeps in device memory (it moves once per step, so no launch
-            # is spent on a counter here and a replayed HIP graph draws fresh masks); the call-site
-            # index tells apart the dropout layers and repeated forwards of one step.  Without one the
-            # module's own counter is used and bumped after each forward.
-            counter = self.step_counter if self.step_counter is not None else self.dropout_rng.state
-            seed = self.dropout_rng.seed + 0x9E3779B97F4A7C15 * (1 + self._drop_calls)
-            self._drop_calls += 1
+        seed, counter = self._dropout_stream(x, drop_p)
         y = _GhostGroupNorm.apply(x, m.weight, m.bias, m.num_groups, m.eps, relu, tape, drop_p, seed, counter)
         if drop_p > 0.0 and self.step_counter is None:
             self.dropout_rng.advance()
