@@ -418,6 +418,19 @@ int vqaf_linear_groupnorm_fwd(const void* x, long ldx, const void* W, long ldw, 
                               uint64_t dropout_seed, const uint64_t* dropout_counter, void* y, void* xhat,
                               float* rstd, vqaf_stream_t stream);
 
+/* The backward of the same pair seen from the NEXT Linear: its input gradient dL/dy = gy W (gy (B,K) bf16
+ * rows ldg apart, K need not be a multiple of 8 when the rows are zero-padded to one; W (K,C) bf16 rows ldw
+ * apart) and, on the output tile, the GroupNorm backward of vqaf_groupnorm_bwd with that call's arguments
+ * (y, xhat, rstd, gamma, relu, out_scale) and outputs (g_pre, grad_x), in ONE launch; dL/dy itself is not
+ * stored.  Equal to vqaf_gemm_bf16 followed by vqaf_groupnorm_bwd bit for bit.  Covered
+ * (vqaf_linear_dgrad_groupnorm_supported): C a multiple of 64, group size 8, 16, 32 or 64, operand rules of
+ * vqaf_gemm_bf16 (k-contiguous gy, k-major W); otherwise VQAF_E_ALIGN. */
+int vqaf_linear_dgrad_groupnorm_supported(long ldg, long ldw, int B, int C, int K, int groups);
+int vqaf_linear_dgrad_groupnorm_bwd(const void* gy, long ldg, const void* W, long ldw, int B, int C, int K,
+                                    const void* y, const void* xhat, const float* rstd, const void* gamma,
+                                    int param_dtype, int groups, int relu, float out_scale, void* g_pre,
+                                    void* grad_x, vqaf_stream_t stream);
+
 /* n <= 4 products of the clipped-sum shape in ONE launch: C_i (M_i,N_i) f32 = A_i^T B_i with A_i (K,M_i) and
  * B_i (K,N_i) bf16, both k-major, the same K (the batch); colsum (array of n pointers, or NULL, entries may be
  * NULL) receives the column sums of A_i; accumulate != 0 adds into C_i / colsum_i.  The clipped sums of the

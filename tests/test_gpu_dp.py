@@ -757,28 +757,47 @@ def test_mean_ce_value_in_one_launch(dev):
 
 
 def test_linear_groupnorm_in_one_launch_equals_the_two_launches(dev):
-    """GroupNorm (+ReLU +Dropout) as the epilogue of the Linear's GEMM: outputs, saved statistics, every
-    tape and the input gradient equal the separate launches bit for bit, for whole and ragged row tiles,
-    group sizes 64 and 32 (the classifier's) and 8, with and without dropout."""
-    from vqa_amd import dp
-    for B, In, C, groups, p in ((256, 1024, 2048, 32, 0.3), (100, 2048, 1024, 32, 0.3), (37, 128, 64, 8, 0.0),
-                                (64, 64, 128, 8, 0.5)):
+    """GroupNorm (+ReLU +Dropout) as the epilogue of the Linear's GEMM, and its backward as the epilogue of
+    the next Linear's input-gradient GEMM: outputs, every tape and the input gradient equal the separate
+    launches bit for bit -- whole and ragged row tiles, group sizes 64 and 32 (the classifier's) and 8, with
+    and without dropout, a head whose width is not a multiple of 8 (the padded loss gradient), and a
+    stand-alone norm between two blocks (no fusion across it)."""
+    from vqa_amd import dp, ops
+
+    def nets(kind, In, C, groups, p):
+        if kind == "two":
+            return [nn.Linear(In, C), nn.GroupNorm(groups, C), nn.ReLU(), nn.Dropout(p), nn.Linear(C, 16)]
+        if kind == "classifier":
+            return [nn.Linear(In, C), nn.GroupNorm(groups, C), nn.ReLU(), nn.Dropout(p),
+                    nn.Linear(C, C // 2), nn.GroupNorm(groups, C // 2), nn.ReLU(), nn.Dropout(p), nn.Linear(C // 2, 430)]
+        return [nn.Linear(In, C), nn.GroupNorm(groups, C), nn.ReLU(), nn.GroupNorm(groups, C), nn.Linear(C, 64),
+                nn.GroupNorm(8, 64), nn.Linear(64, 16)]
+
+    cases = (("two", 256, 1024, 2048, 32, 0.3), ("two", 100, 2048, 1024, 32, 0.3), ("two", 37, 128, 64, 8, 0.0),
+             ("two", 64, 64, 128, 8, 0.5), ("classifier", 130, 256, 512, 32, 0.3), ("mixed", 70, 128, 256, 32, 0.0))
+    for kind, B, In, C, groups, p in cases:
         outs = []
         for fuse in (False, True):
             torch.manual_seed(5)
-            m = nn.Sequential(nn.Linear(In, C), nn.GroupNorm(groups, C), nn.ReLU(), nn.Dropout(p), nn.Linear(C, 10)).to(dev)
+            m = nn.Sequential(*nets(kind, In, C, groups, p)).to(dev)
             gsm = dp.GradSampleModule(m)
             gsm.fuse_linear_groupnorm = fuse
             gsm.train()
             x = gi.normal(3, B, In).to(dev).bfloat16().requires_grad_()
             torch.manual_seed(11)  # the dropout stream is seeded from torch's global seed on first use
             y = gsm(x)
-            y.float().square().sum().backward()
+            if kind == "classifier":
+                tgt = gi.labels(7, B, 430).to(dev)
+                loss = ops.cross_entropy_mean(y, tgt)
+                loss.backward(gradient=ops.unit_gradient(loss))
+            else:
+                y.float().square().sum().backward()
             tapes = [(t.a.clone(), t.g.clone()) for t in gsm.tapes]
-            outs.append((y.detach().clone(), x.grad.clone(), tapes, len(gsm.tapes)))
-        (y0, gx0, t0, n0), (y1, gx1, t1, n1) = outs
-        assert n0 == n1 == 3
-        assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
-        assert float(y0.float().abs().sum()) > 0
+            outs.append((y.detach().clone(), x.grad.clone(), tapes))
+        (y0, gx0, t0), (y1, gx1, t1) = outs
+        assert len(t0) == len(t1) == {"two": 3, "classifier": 5, "mixed": 6}[kind]
+        assert torch.equal(y0, y1) and torch.equal(gx0, gx1), kind
+        assert float(y0.float().abs().sum()) > 0 and float(gx0.float().abs().sum()) > 0
         for (a0, g0), (a1, g1) in zip(t0, t1):
-            assert torch.equal(a0, a1) and torch.equal(g0, g1)
+            assert a0.shape == a1.shape and g0.shape == g1.shape
+            assert torch.equal(a0, a1) and torch.equal(g0, g1), kind

@@ -112,6 +112,9 @@ SIGNATURES = {
                                      c_float, c_int, _P]),
     "vqaf_gemm_bf16_supported": (c_int, [c_long, c_int, c_long, c_int, c_int, c_int, c_int]),
     "vqaf_linear_groupnorm_supported": (c_int, [c_long, c_long, c_int, c_int, c_int, c_int]),
+    "vqaf_linear_dgrad_groupnorm_supported": (c_int, [c_long, c_long, c_int, c_int, c_int, c_int]),
+    "vqaf_linear_dgrad_groupnorm_bwd": (c_int, [_P, c_long, _P, c_long, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int,
+                                                c_int, c_float, _P, _P, _P]),
     "vqaf_linear_groupnorm_fwd": (c_int, [_P, c_long, _P, c_long, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int,
                                           c_float, c_int, c_float, c_uint64, _P, _P, _P, _P, _P]),
     "vqaf_gemm_bf16_wgrad_group": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, _P, _P]),

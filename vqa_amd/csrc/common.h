@@ -109,6 +109,48 @@ __device__ __forceinline__ void store1(void* base, size_t e, float v) {
   else reinterpret_cast<float*>(base)[e] = v;
 }
 
+// GroupNorm backward of eight consecutive channels of one row whose group spans `lpg` adjacent lanes
+// (gs = 8 * lpg channels): dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) with g = gy * gamma.
+// Every operation is pinned (no contraction left to the compiler), so the kernels that share this
+// function produce the same bits.
+__device__ __forceinline__ void vqaf_gn_bwd8(const float (&gy)[8], const float (&xh)[8], const float (&ga)[8],
+                                             int lpg, int gs, float rs, float (&dx)[8]) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    dx[i] = __fmul_rn(gy[i], ga[i]);
+    s1 = __fadd_rn(s1, dx[i]);
+    s2 = fmaf(dx[i], xh[i], s2);
+  }
+  for (int o = lpg >> 1; o > 0; o >>= 1) {
+    s1 = __fadd_rn(s1, __shfl_xor(s1, o, 64));
+    s2 = __fadd_rn(s2, __shfl_xor(s2, o, 64));
+  }
+  const float m1 = __fdiv_rn(s1, (float)gs), m2 = __fdiv_rn(s2, (float)gs);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dx[i] = __fmul_rn(rs, fmaf(-xh[i], m2, __fsub_rn(dx[i], m1)));
+}
+
+// GroupNorm forward of eight consecutive channels (same layout): v <- (v - mean) * rstd, returns rstd.
+__device__ __forceinline__ float vqaf_gn_fwd8(float (&v)[8], int lpg, int gs, float eps) {
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sm = __fadd_rn(sm, v[i]);
+  for (int o = lpg >> 1; o > 0; o >>= 1) sm = __fadd_rn(sm, __shfl_xor(sm, o, 64));
+  const float mean = __fdiv_rn(sm, (float)gs);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = __fsub_rn(v[i], mean);
+    q = fmaf(v[i], v[i], q);
+  }
+  for (int o = lpg >> 1; o > 0; o >>= 1) q = __fadd_rn(q, __shfl_xor(q, o, 64));
+  const float rs = rsqrtf(__fadd_rn(__fdiv_rn(q, (float)gs), eps));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = __fmul_rn(v[i], rs);
+  return rs;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

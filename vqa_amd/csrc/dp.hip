@@ -831,21 +831,9 @@ groupnorm_fwd_kernel(const void* __restrict__ x, const void* __restrict__ gamma,
     float v[8], rsv[8];
     load8<BF16>(x, (size_t)b * C + c0, v);
     if (gs >= 8) {
-      float s = 0.f;
+      const float rs = vqaf_gn_fwd8(v, lpg, gs, eps);  // v is normalised on return
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s += v[i];
-      for (int o = lpg >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      const float mean = s / (float)gs;
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v[i] -= mean;
-        q = fmaf(v[i], v[i], q);
-      }
-      for (int o = lpg >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-      const float rs = rsqrtf(q / (float)gs + eps);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) rsv[i] = rs;
+      for (int i = 0; i < 8; ++i) rsv[i] = 1.f;
       if ((threadIdx.x % lpg) == 0) rstd[(size_t)b * groups + c0 / gs] = rs;
     } else {
       // several groups inside one lane's 8 channels (gs in {1,2,4}): segmented butterflies
@@ -923,21 +911,7 @@ groupnorm_bwd_kernel(const void* __restrict__ grad_y, const void* __restrict__ y
     store8<BF16>(g_pre, (size_t)b * C + c0, gy);
     float dx[8];
     if (gs >= 8) {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        dx[i] = gy[i] * ga[i];
-        s1 += dx[i];
-        s2 = fmaf(dx[i], xh[i], s2);
-      }
-      for (int o = lpg >> 1; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-      }
-      const float rs = rstd[(size_t)b * groups + c0 / gs];
-      const float m1 = s1 / (float)gs, m2 = s2 / (float)gs;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) dx[i] = rs * (dx[i] - m1 - xh[i] * m2);
+      vqaf_gn_bwd8(gy, xh, ga, lpg, gs, rstd[(size_t)b * groups + c0 / gs], dx);
     } else {
       float s1[8], s2[8];
 #pragma unroll

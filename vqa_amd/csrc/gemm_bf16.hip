@@ -63,6 +63,13 @@ struct GnEpi {
   unsigned long long drop_seed;
   float eps, drop_p;
   int groups, relu, param_bf16;
+  // backward form (the GEMM is the input gradient of the NEXT Linear; its output is dL/dy of this norm)
+  const void* y_in;     // (M,N) bf16: the forward output (ReLU gate and dropout keep mask), or NULL without ReLU
+  const void* xhat_in;  // (M,N) bf16
+  const float* rstd_in; // (M, groups)
+  void* g_pre;          // (M,N) bf16: gradient at the affine output (the norm layer's backprop record)
+  void* grad_x;         // (M,N) bf16: gradient at the norm's input (= the output of the Linear in front of it)
+  float out_scale;      // 1 / (1 - p) of the inverted dropout, 1 without it
 };
 
 __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
@@ -226,6 +233,19 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile
   gb_bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  // backward GroupNorm epilogue: its operands (two 16-byte pieces per thread and row pass) are requested
+  // now and used after the k loop
+  u32x4 epi_y[2], epi_xh[2];
+  if constexpr (EPI == 2) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int mb = min(m0 + (tid >> 3) + 32 * pass, g.M - 1);
+      const size_t off = (size_t)mb * g.N + n0 + 8 * (tid & 7);
+      epi_xh[pass] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(epi->xhat_in) + off);
+      epi_y[pass] = epi->y_in != nullptr ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(epi->y_in) + off)
+                                         : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
 
   // Fragment reads are inline assembly on purpose: for an LDS read it can see, hipcc waits until
   // EVERY outstanding LDS-DMA has landed (vmcnt(0)), which would drain the ring at each k-step.
@@ -371,23 +391,10 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile
       const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * TP + 8 * chunk + 4);
       v[0] = t0[0]; v[1] = t0[1]; v[2] = t0[2]; v[3] = t0[3];
       v[4] = t1[0]; v[5] = t1[1]; v[6] = t1[2]; v[7] = t1[3];
-      float sm = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) sm += v[i];
-      for (int o = lpg >> 1; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
-      const float mean = sm / (float)gs;
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v[i] -= mean;
-        q = fmaf(v[i], v[i], q);
-      }
-      for (int o = lpg >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-      const float rs = rsqrtf(q / (float)gs + e.eps);
+      const float rs = vqaf_gn_fwd8(v, lpg, gs, e.eps);  // v is normalised on return
       float yo[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        v[i] *= rs;
         yo[i] = fmaf(v[i], ga[i], be[i]);
         if (e.relu) yo[i] = fmaxf(yo[i], 0.f);
       }
@@ -404,6 +411,51 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile
         if ((chunk % lpg) == 0) e.rstd[(size_t)m * e.groups + c0 / gs] = rs;
         store8<true>(e.y, (size_t)m * C + c0, yo);
         store8<true>(e.xhat, (size_t)m * C + c0, v);
+      }
+    }
+    return;
+  }
+  if constexpr (EPI == 2) {
+    // GroupNorm backward on the tile of dL/dy this GEMM just produced (same staging and thread layout as the
+    // forward epilogue; the tile is rounded to bf16 first and the sums follow vqaf_groupnorm_bwd's order).
+    static_assert(MT == 1 && !A_KMAJOR && B_KMAJOR && !COLSUM, "GroupNorm backward epilogue: dgrad tiles of 64 x 64");
+    constexpr int TP = 68;
+    float* T = reinterpret_cast<float*>(gb_lds);
+    const GnEpi& e = *epi;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      T[row * TP + wn * 32 + (lane & 31)] = bf16_to_f32(f32_to_bf16(acc[0][r]));
+    }
+    __syncthreads();
+    const int C = g.N, gs = C / e.groups, lpg = gs / 8;
+    const int chunk = tid & 7, c0 = n0 + 8 * chunk;
+    float ga[8];
+    if (e.param_bf16) load8<true>(e.gamma, (size_t)c0, ga);
+    else load8<false>(e.gamma, (size_t)c0, ga);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = (tid >> 3) + 32 * pass, m = m0 + row;
+      const int mb = min(m, g.M - 1);
+      float gy[8], xh[8], yo[8];
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * TP + 8 * chunk);
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * TP + 8 * chunk + 4);
+      gy[0] = t0[0]; gy[1] = t0[1]; gy[2] = t0[2]; gy[3] = t0[3];
+      gy[4] = t1[0]; gy[5] = t1[1]; gy[6] = t1[2]; gy[7] = t1[3];
+      xh[0] = bf16_lo(epi_xh[pass].x); xh[1] = bf16_hi(epi_xh[pass].x); xh[2] = bf16_lo(epi_xh[pass].y); xh[3] = bf16_hi(epi_xh[pass].y);
+      xh[4] = bf16_lo(epi_xh[pass].z); xh[5] = bf16_hi(epi_xh[pass].z); xh[6] = bf16_lo(epi_xh[pass].w); xh[7] = bf16_hi(epi_xh[pass].w);
+      if (e.relu) {
+        yo[0] = bf16_lo(epi_y[pass].x); yo[1] = bf16_hi(epi_y[pass].x); yo[2] = bf16_lo(epi_y[pass].y); yo[3] = bf16_hi(epi_y[pass].y);
+        yo[4] = bf16_lo(epi_y[pass].z); yo[5] = bf16_hi(epi_y[pass].z); yo[6] = bf16_lo(epi_y[pass].w); yo[7] = bf16_hi(epi_y[pass].w);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gy[i] = yo[i] > 0.f ? gy[i] * e.out_scale : 0.f;
+      }
+      float dx[8];
+      vqaf_gn_bwd8(gy, xh, ga, lpg, gs, e.rstd_in[(size_t)mb * e.groups + c0 / gs], dx);
+      if (m < g.M) {
+        store8<true>(e.g_pre, (size_t)m * C + c0, gy);
+        store8<true>(e.grad_x, (size_t)m * C + c0, dx);
       }
     }
     return;
@@ -468,6 +520,14 @@ gemm_bf16_gn_kernel(GemmArgs g, GnEpi e) {
   int tile_m, tile_n;
   tile_of(g, (int)blockIdx.x, tile_m, tile_n);
   gemm_bf16_body<1, false, false, false, STAGES, 1>(g, tile_m, tile_n, &e);
+}
+
+template <int STAGES>
+__global__ void __launch_bounds__(2 * GB_THREADS)
+gemm_bf16_gn_bwd_kernel(GemmArgs g, GnEpi e) {
+  int tile_m, tile_n;
+  tile_of(g, (int)blockIdx.x, tile_m, tile_n);
+  gemm_bf16_body<1, false, true, false, STAGES, 2>(g, tile_m, tile_n, &e);
 }
 
 // Several weight-gradient-shaped products (both operands k-major, the same contraction length) in ONE
@@ -551,6 +611,19 @@ int launch_gemm_gn(const GemmArgs& g, const GnEpi& e, dim3 grid, hipStream_t st)
   return hipGetLastError() == hipSuccess ? VQAF_OK : VQAF_E_LAUNCH;
 }
 
+template <int STAGES>
+int launch_gemm_gn_bwd(const GemmArgs& g, const GnEpi& e, dim3 grid, hipStream_t st) {
+  constexpr size_t smem = (size_t)STAGES * (64 + GB_BN) * GB_BK * 2;
+  static_assert(smem >= 64 * 68 * sizeof(float), "the staged output tile lives in the operand ring");
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_gn_bwd_kernel<STAGES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  hipLaunchKernelGGL((gemm_bf16_gn_bwd_kernel<STAGES>), grid, dim3(2 * GB_THREADS), smem, st, g, e);
+  return hipGetLastError() == hipSuccess ? VQAF_OK : VQAF_E_LAUNCH;
+}
+
 // 8 equal regions of the tile grid (one per XCD), as square as the tile counts allow; 0, 0 if none divides
 void pick_regions(int tiles_m, int tiles_n, int BM, int& reg_m, int& reg_n) {
   reg_m = reg_n = 0;
@@ -614,6 +687,53 @@ extern "C" int vqaf_linear_groupnorm_fwd(const void* x, long ldx, const void* W,
   const long tiles128 = (long)((B + 127) / 128) * (C / 64);
   if (tiles128 >= 200 && tiles128 <= 512 && K <= 2048 && B <= 4096) return launch_gemm_gn<3>(g, e, grid, (hipStream_t)stream);
   return launch_gemm_gn<GB_STAGES>(g, e, grid, (hipStream_t)stream);
+}
+
+extern "C" int vqaf_linear_dgrad_groupnorm_supported(long ldg, long ldw, int B, int C, int K, int groups) {
+  if (groups <= 0 || C % groups != 0 || C % 64 != 0) return 0;
+  const int gs = C / groups;
+  if (!(gs == 8 || gs == 16 || gs == 32 || gs == 64)) return 0;
+  return vqaf_gemm_bf16_supported(ldg, 0, ldw, 1, B, C, K);
+}
+
+extern "C" int vqaf_linear_dgrad_groupnorm_bwd(const void* gy, long ldg, const void* W, long ldw, int B, int C, int K,
+                                               const void* y, const void* xhat, const float* rstd, const void* gamma,
+                                               int param_dtype, int groups, int relu, float out_scale, void* g_pre,
+                                               void* grad_x, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(gy && W && xhat && rstd && gamma && g_pre && grad_x, VQAF_E_NULL);
+  VQAF_REQUIRE(!relu || y != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(relu || out_scale == 1.0f, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_dtype_ok(param_dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(B > 0 && C > 0 && K > 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(vqaf_linear_dgrad_groupnorm_supported(ldg, ldw, B, C, K, groups), VQAF_E_ALIGN);
+  VQAF_REQUIRE(vqaf_aligned16(gy) && vqaf_aligned16(W) && vqaf_aligned16(xhat) && vqaf_aligned16(g_pre) &&
+                   vqaf_aligned16(grad_x) && vqaf_aligned16(gamma) && (y == nullptr || vqaf_aligned16(y)), VQAF_E_ALIGN);
+  const unsigned int* zeros = nullptr;
+  const int rc = zero_block_on_current_device(&zeros);
+  if (rc != VQAF_OK) return rc;
+  GemmArgs g;
+  g.A = reinterpret_cast<const bf16_t*>(gy);
+  g.B = reinterpret_cast<const bf16_t*>(W);
+  g.bias = nullptr;
+  g.C = nullptr;
+  g.colsum = nullptr;
+  g.zeros = zeros;
+  g.lda = ldg; g.ldb = ldw; g.ldc = C;
+  g.M = B; g.N = C; g.K = K;
+  g.k_per_split = (K + GB_BK - 1) / GB_BK * GB_BK;
+  g.tiles_m = (B + 63) / 64; g.tiles_n = C / 64;
+  pick_regions(g.tiles_m, g.tiles_n, 64, g.reg_m, g.reg_n);
+  g.bias_bf16 = 0;
+  g.out_mode = GB_OUT_BF16;
+  GnEpi e = {};
+  e.gamma = gamma; e.groups = groups; e.relu = relu; e.param_bf16 = param_dtype == VQAF_BF16 ? 1 : 0;
+  e.y_in = relu ? y : nullptr; e.xhat_in = xhat; e.rstd_in = rstd; e.g_pre = g_pre; e.grad_x = grad_x;
+  e.out_scale = out_scale;
+  const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, 1);
+  const long tiles128 = (long)((B + 127) / 128) * (C / 64);
+  if (tiles128 >= 200 && tiles128 <= 512 && K <= 2048 && B <= 4096) return launch_gemm_gn_bwd<3>(g, e, grid, (hipStream_t)stream);
+  return launch_gemm_gn_bwd<GB_STAGES>(g, e, grid, (hipStream_t)stream);
 }
 
 extern "C" int vqaf_gemm_bf16_supported(long lda, int a_kmajor, long ldb, int b_kmajor, int M, int N, int K) {

@@ -105,12 +105,44 @@ def _as_dtype(p: torch.Tensor, dtype: torch.dtype, shadow) -> torch.Tensor:
     return p.to(dtype)
 
 
+class _GnLink:
+    """What a fused Linear -> GroupNorm block leaves for the Linear that consumes its output: that
+    Linear's backward can run the norm's backward as the epilogue of its input-gradient GEMM
+    (vqaf_linear_dgrad_groupnorm_bwd) and hands back the gradient at the norm's INPUT; `done` tells the
+    block's own backward that its incoming gradient is already that one."""
+
+    __slots__ = ("y", "xhat", "rstd", "ga", "groups", "relu", "out_scale", "gn_tape", "done")
+
+    def __init__(self):
+        self.y = self.xhat = self.rstd = self.ga = self.gn_tape = None
+        self.groups, self.relu, self.out_scale, self.done = 0, 0, 1.0, False
+
+
+def _dgrad_with_norm_backward(link, gy, w, Bn, In, Out):
+    """gx = GroupNorm_backward(gy W) in one launch when `link` describes the norm in front and the shapes are
+    covered; None otherwise.  Fills the norm layer's tape."""
+    if link is None or link.xhat is None or gy.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or \
+            not w.is_contiguous() or link.xhat.shape != (Bn, In):
+        return None
+    if not load().vqaf_linear_dgrad_groupnorm_supported(gy.stride(0), In, Bn, In, Out, link.groups):
+        return None
+    g_pre = torch.empty_like(link.xhat)
+    gl = torch.empty_like(link.xhat)
+    check(load().vqaf_linear_dgrad_groupnorm_bwd(
+        gy.data_ptr(), gy.stride(0), ptr(w), In, Bn, In, Out, ptr(link.y) if link.relu else None, ptr(link.xhat),
+        ptr(link.rstd), ptr(link.ga), dtype_code(link.ga), link.groups, int(link.relu), float(link.out_scale),
+        ptr(g_pre), ptr(gl), stream_ptr(gy.device)), "vqaf_linear_dgrad_groupnorm_bwd")
+    link.gn_tape.a, link.gn_tape.g = link.xhat, g_pre
+    link.done = True
+    return gl
+
+
 class _GhostLinear(torch.autograd.Function):
     """y = x W^T + b through the vendor GEMM; backward returns only dL/dx and records dL/dy.
     The weight gradient is NOT computed here -- the clipped sum replaces it."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, tape):
+    def forward(ctx, x, weight, bias, tape, link=None):
         w = _as_dtype(weight, x.dtype, tape.shadow)
         b = None if bias is None else _as_dtype(bias, x.dtype, tape.shadow)
         Bn, In = x.shape
@@ -125,6 +157,7 @@ class _GhostLinear(torch.autograd.Function):
             y = F.linear(x, w, b)
         ctx.save_for_backward(w)
         ctx.tape = tape
+        ctx.link = link
         tape.a = xc.detach()
         return y
 
@@ -135,16 +168,19 @@ class _GhostLinear(torch.autograd.Function):
             gy = gy.contiguous()
         ctx.tape.g = gy
         if not ctx.needs_input_grad[0]:
-            return None, None, None, None
+            return None, None, None, None, None
         Bn, Out = gy.shape
         In = w.shape[1]
+        gl = _dgrad_with_norm_backward(ctx.link, gy, w, Bn, In, Out)
+        if gl is not None:
+            return gl, None, None, None, None
         if gy.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.is_contiguous() and \
                 ops.gemm_bf16_supported(gy.stride(0), False, In, True, Bn, In, Out):
             gx = torch.empty(Bn, In, dtype=torch.bfloat16, device=gy.device)
             ops.gemm_bf16(gy, False, w, True, Bn, In, Out, gx)
         else:
             gx = gy.matmul(w)
-        return gx, None, None, None
+        return gx, None, None, None, None
 
 
 class _GhostGroupNorm(torch.autograd.Function):
@@ -193,7 +229,7 @@ class _GhostLinearGroupNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gn_weight, gn_bias, groups, eps, relu, lin_tape, gn_tape, drop_p=0.0,
-                drop_seed=0, drop_counter=None):
+                drop_seed=0, drop_counter=None, link_in=None, link_out=None):
         w = _as_dtype(weight, x.dtype, lin_tape.shadow)
         b = None if bias is None else _as_dtype(bias, x.dtype, lin_tape.shadow)
         ga = _as_dtype(gn_weight.detach(), x.dtype, gn_tape.shadow).contiguous()
@@ -212,6 +248,13 @@ class _GhostLinearGroupNorm(torch.autograd.Function):
         ctx.save_for_backward(w, y, xhat, rstd, ga)
         ctx.meta = (Bn, C, groups, int(relu), 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0)
         ctx.tapes = (lin_tape, gn_tape)
+        ctx.links = (link_in, link_out)
+        if link_out is not None:
+            # (y detached: the link must not reach this node through its own output, or the step's autograd
+            # graph would stay alive until the cycle collector runs)
+            link_out.y, link_out.xhat, link_out.rstd, link_out.ga = y.detach(), xhat, rstd, ga
+            link_out.groups, link_out.relu, link_out.out_scale = groups, int(relu), ctx.meta[4]
+            link_out.gn_tape, link_out.done = gn_tape, False
         lin_tape.a = xc.detach()
         return y
 
@@ -220,18 +263,27 @@ class _GhostLinearGroupNorm(torch.autograd.Function):
         w, y, xhat, rstd, ga = ctx.saved_tensors
         Bn, C, groups, relu, out_scale = ctx.meta
         lin_tape, gn_tape = ctx.tapes
-        gy = gy.contiguous().to(y.dtype)
-        g_pre = torch.empty_like(y)
-        gl = torch.empty_like(y)  # gradient at the Linear's output
-        check(load().vqaf_groupnorm_bwd(ptr(gy), ptr(y), ptr(xhat), ptr(rstd), ptr(ga), Bn, C, groups, relu,
-                                        float(out_scale), dtype_code(y), ptr(g_pre), ptr(gl), stream_ptr(y.device)),
-              "vqaf_groupnorm_bwd")
-        gn_tape.a, gn_tape.g = xhat, g_pre
+        link_in, link_out = ctx.links
+        if link_out is not None and link_out.done:
+            # the consuming Linear ran this norm's backward on its input-gradient tile: gy IS the gradient
+            # at this block's Linear output, and the norm's tape is filled
+            gl = gy
+        else:
+            gy = gy.contiguous().to(y.dtype)
+            g_pre = torch.empty_like(y)
+            gl = torch.empty_like(y)  # gradient at the Linear's output
+            check(load().vqaf_groupnorm_bwd(ptr(gy), ptr(y), ptr(xhat), ptr(rstd), ptr(ga), Bn, C, groups, relu,
+                                            float(out_scale), dtype_code(y), ptr(g_pre), ptr(gl),
+                                            stream_ptr(y.device)), "vqaf_groupnorm_bwd")
+            gn_tape.a, gn_tape.g = xhat, g_pre
         lin_tape.g = gl
-        none = (None,) * 12
+        none = (None,) * 14
         if not ctx.needs_input_grad[0]:
             return (None,) + none
         In = w.shape[1]
+        gin = _dgrad_with_norm_backward(link_in, gl, w, Bn, In, C)
+        if gin is not None:
+            return (gin,) + none
         if ops.gemm_bf16_supported(C, False, In, True, Bn, In, C):
             gx = torch.empty(Bn, In, dtype=torch.bfloat16, device=gy.device)
             ops.gemm_bf16(gl, False, w, True, Bn, In, C, gx)
@@ -284,6 +336,7 @@ class GradSampleModule(nn.Module):
 
     def forward(self, x):
         self.tapes = []
+        self._link = None
         self.last_batch_size = x.shape[0]
         if self.input_grad_scale is not None and x.requires_grad:
             x = _ScaleGrad.apply(x, self.input_grad_scale)
@@ -309,7 +362,8 @@ class GradSampleModule(nn.Module):
                         else:
                             p = float(drop.p) if (drop.training and 0.0 < drop.p < 1.0) else 0.0
                     if self._linear_groupnorm_ok(c, gn, x):
-                        x = self._linear_groupnorm(c, gn, x, relu=relu, drop_p=p)
+                        link_in, self._link = self._link, _GnLink()
+                        x = self._linear_groupnorm(c, gn, x, relu=relu, drop_p=p, link_in=link_in, link_out=self._link)
                         i += 2 + (1 if relu else 0) + (1 if drop is not None else 0)
                         continue
                 if isinstance(c, nn.GroupNorm) and i + 1 < len(children) and \
@@ -331,12 +385,13 @@ class GradSampleModule(nn.Module):
                 x = self._run(c, x)
                 i += 1
             return x
+        link, self._link = self._link, None  # only the module that directly consumes a fused block's output may use it
         if isinstance(m, nn.Linear):
             if x.dim() != 2:
                 raise ValueError("per-sample rule implemented for Linear on (B, features) input")
             tape = _Tape(m, "linear", self.shadow)
             self.tapes.append(tape)
-            return _GhostLinear.apply(x, m.weight, m.bias, tape)
+            return _GhostLinear.apply(x, m.weight, m.bias, tape, link)
         if isinstance(m, nn.GroupNorm):
             return self._groupnorm(m, x, relu=False)
         if next(m.parameters(), None) is None:
@@ -367,13 +422,14 @@ class GradSampleModule(nn.Module):
         self._drop_calls += 1
         return seed, counter
 
-    def _linear_groupnorm(self, lin: nn.Linear, gn: nn.GroupNorm, x, relu: bool, drop_p: float = 0.0):
+    def _linear_groupnorm(self, lin: nn.Linear, gn: nn.GroupNorm, x, relu: bool, drop_p: float = 0.0,
+                          link_in=None, link_out=None):
         lin_tape = _Tape(lin, "linear", self.shadow)
         gn_tape = _Tape(gn, "affine", self.shadow)
         self.tapes += [lin_tape, gn_tape]
         seed, counter = self._dropout_stream(x, drop_p)
         y = _GhostLinearGroupNorm.apply(x, lin.weight, lin.bias, gn.weight, gn.bias, gn.num_groups, gn.eps, relu,
-                                        lin_tape, gn_tape, drop_p, seed, counter)
+                                        lin_tape, gn_tape, drop_p, seed, counter, link_in, link_out)
         if drop_p > 0.0 and self.step_counter is None:
             self.dropout_rng.advance()
         return y
@@ -381,6 +437,7 @@ class GradSampleModule(nn.Module):
     def _groupnorm(self, m: nn.GroupNorm, x, relu: bool, drop_p: float = 0.0):
         if x.dim() != 2 or not m.affine:
             raise ValueError("per-sample rule implemented for affine GroupNorm on (B, C) input")
+        self._link = None  # a stand-alone norm consumes the previous block's output itself
         tape = _Tape(m, "affine", self.shadow)
         self.tapes.append(tape)
         seed, counter = self._dropout_stream(x, drop_p)
