@@ -477,6 +477,15 @@ int vqaf_ghost_clip(int n_layers, const void* const* a_host, const void* const* 
                     int dtype, float max_norm, float scale, int scale_g_inplace, float* coef,
                     float* norms, float* sq, vqaf_stream_t stream);
 
+/* vqaf_ghost_clip that also clears n_zero <= 8 ranges of f32 (HOST arrays of device pointers and element
+ * counts) in the same launch: the sums the following kernels build with atomic adds (what a separate
+ * vqaf_zero_multi launch would do).  The ranges must not overlap anything the launch reads. */
+int vqaf_ghost_clip_zero(int n_layers, const void* const* a_host, const void* const* g_host,
+                         const int* in_dim_host, const int* out_dim_host, const int* kind_host, int B,
+                         int dtype, float max_norm, float scale, int scale_g_inplace, float* coef,
+                         float* norms, float* sq, float* const* zero_ptrs_host,
+                         const size_t* zero_counts_host, int n_zero, vqaf_stream_t stream);
+
 /* Clipped gradient sum of a Linear:  SW (Out,In) f32 = sum_b coef[b] g_b a_b^T,
  * Sb (Out) f32 = sum_b coef[b] g_b (Sb may be NULL).  bf16 inputs use bf16 MFMA, f32
  * inputs the exact f32 MFMA.  accumulate != 0 adds into SW / Sb (micro-batching).

@@ -125,6 +125,8 @@ SIGNATURES = {
     "vqaf_clip_coef": (c_int, [_P, c_int, c_float, c_float, _P, _P, _P]),
     "vqaf_ghost_clip": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int, _P, _P, _P,
                                 _P]),
+    "vqaf_ghost_clip_zero": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int, _P, _P, _P,
+                                     _P, _P, c_int, _P]),
     "vqaf_clipped_sum_linear": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_clipped_sum_affine": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_clipped_sum_affine_multi": (c_int, [c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P]),

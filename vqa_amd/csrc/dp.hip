@@ -74,6 +74,20 @@ constexpr int GC_MAX_LAYERS = 8;
 __device__ __forceinline__ bool vqaf_dev_aligned16(const void* p) {
   return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
+// Ranges of f32 that a launch clears on the side (sums that later kernels build with atomic adds).
+constexpr int GC_MAX_ZERO = 8;
+struct GhostZero {
+  float* p[GC_MAX_ZERO];
+  unsigned int n[GC_MAX_ZERO];  // elements
+  int count;
+};
+__device__ __forceinline__ void ghost_zero_ranges(const GhostZero& Z) {
+  const unsigned int stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < GC_MAX_ZERO; ++r)
+    if (r < Z.count)
+      for (unsigned int i = first; i < Z.n[r]; i += stride) Z.p[r][i] = 0.f;
+}
 struct GhostLayers {
   const void* a[GC_MAX_LAYERS];
   const void* g[GC_MAX_LAYERS];
@@ -141,7 +155,7 @@ __device__ __forceinline__ unsigned int scale_bf16x2(unsigned int w, float c) {
 // layer, and the in-place scaling g <- c g reuses the registers instead of reading the rows again.
 __global__ void __launch_bounds__(DP_THREADS, 4)
 ghost_clip_rows_kernel(GhostLayers L, float max_norm, float scale, int scale_g, float* __restrict__ coef,
-                       float* __restrict__ norms, float* __restrict__ sq_out) {
+                       float* __restrict__ norms, float* __restrict__ sq_out, GhostZero Z) {
   __shared__ float red[DP_THREADS / 64][2 * GC_MAX_LAYERS];
   __shared__ float s_coef;
   const int b = blockIdx.x, i0 = threadIdx.x * 8;
@@ -157,6 +171,7 @@ ghost_clip_rows_kernel(GhostLayers L, float max_norm, float scale, int scale_g, 
       if (i0 < Out) rg[l] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(L.g[l]) + (size_t)b * Out + i0);
     }
   }
+  ghost_zero_ranges(Z);  // while the rows are on their way
   float part[2 * GC_MAX_LAYERS];
 #pragma unroll
   for (int l = 0; l < GC_MAX_LAYERS; ++l) {
@@ -194,11 +209,12 @@ ghost_clip_rows_kernel(GhostLayers L, float max_norm, float scale, int scale_g, 
 template <bool BF16>
 __global__ void __launch_bounds__(DP_THREADS)
 ghost_clip_kernel(GhostLayers L, float max_norm, float scale, int scale_g, float* __restrict__ coef,
-                  float* __restrict__ norms, float* __restrict__ sq_out) {
+                  float* __restrict__ norms, float* __restrict__ sq_out, GhostZero Z) {
   constexpr int NW = DP_THREADS / 64, SPAN = DP_THREADS * 8;
   __shared__ float red[NW][2 * GC_MAX_LAYERS];
   __shared__ float s_coef;
   const int b = blockIdx.x, tid = threadIdx.x, i0 = tid * 8;
+  ghost_zero_ranges(Z);
   // per-thread partial sums: [2l] = ||a||^2 part (Linear) or the whole affine term, [2l+1] = ||g||^2 part
   float part[2 * GC_MAX_LAYERS];
 #pragma unroll
@@ -1120,11 +1136,10 @@ extern "C" int vqaf_clip_coef(const float* sq, int B, float max_norm, float scal
   VQAF_LAUNCH_CHECK();
 }
 
-extern "C" int vqaf_ghost_clip(int n_layers, const void* const* a_host, const void* const* g_host,
-                               const int* in_dim_host, const int* out_dim_host, const int* kind_host,
-                               int B, int dtype, float max_norm, float scale, int scale_g_inplace,
-                               float* coef, float* norms, float* sq, vqaf_stream_t stream) {
-  VQAF_ENTRY();
+static int ghost_clip_launch(int n_layers, const void* const* a_host, const void* const* g_host,
+                             const int* in_dim_host, const int* out_dim_host, const int* kind_host,
+                             int B, int dtype, float max_norm, float scale, int scale_g_inplace,
+                             float* coef, float* norms, float* sq, const GhostZero& Z, vqaf_stream_t stream) {
   VQAF_REQUIRE(a_host && g_host && in_dim_host && out_dim_host && kind_host && coef, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(B > 0 && n_layers > 0 && n_layers <= GC_MAX_LAYERS, VQAF_E_SHAPE);
@@ -1152,14 +1167,44 @@ extern "C" int vqaf_ghost_clip(int n_layers, const void* const* a_host, const vo
   }
   if (rows_fit)
     hipLaunchKernelGGL(ghost_clip_rows_kernel, dim3(B), dim3(DP_THREADS), 0, (hipStream_t)stream, L,
-                       max_norm, scale, scale_g_inplace, coef, norms, sq);
+                       max_norm, scale, scale_g_inplace, coef, norms, sq, Z);
   else if (dtype == VQAF_BF16)
     hipLaunchKernelGGL(ghost_clip_kernel<true>, dim3(B), dim3(DP_THREADS), 0, (hipStream_t)stream, L,
-                       max_norm, scale, scale_g_inplace, coef, norms, sq);
+                       max_norm, scale, scale_g_inplace, coef, norms, sq, Z);
   else
     hipLaunchKernelGGL(ghost_clip_kernel<false>, dim3(B), dim3(DP_THREADS), 0, (hipStream_t)stream, L,
-                       max_norm, scale, scale_g_inplace, coef, norms, sq);
+                       max_norm, scale, scale_g_inplace, coef, norms, sq, Z);
   VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_ghost_clip(int n_layers, const void* const* a_host, const void* const* g_host,
+                               const int* in_dim_host, const int* out_dim_host, const int* kind_host,
+                               int B, int dtype, float max_norm, float scale, int scale_g_inplace,
+                               float* coef, float* norms, float* sq, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  GhostZero Z = {};
+  return ghost_clip_launch(n_layers, a_host, g_host, in_dim_host, out_dim_host, kind_host, B, dtype, max_norm, scale,
+                           scale_g_inplace, coef, norms, sq, Z, stream);
+}
+
+extern "C" int vqaf_ghost_clip_zero(int n_layers, const void* const* a_host, const void* const* g_host,
+                                    const int* in_dim_host, const int* out_dim_host, const int* kind_host,
+                                    int B, int dtype, float max_norm, float scale, int scale_g_inplace,
+                                    float* coef, float* norms, float* sq, float* const* zero_ptrs_host,
+                                    const size_t* zero_counts_host, int n_zero, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(n_zero >= 0 && n_zero <= GC_MAX_ZERO, VQAF_E_SHAPE);
+  VQAF_REQUIRE(n_zero == 0 || (zero_ptrs_host && zero_counts_host), VQAF_E_NULL);
+  GhostZero Z = {};
+  for (int i = 0; i < n_zero; ++i) {
+    VQAF_REQUIRE(zero_ptrs_host[i] != nullptr, VQAF_E_NULL);
+    VQAF_REQUIRE(zero_counts_host[i] < (1ull << 32), VQAF_E_SHAPE);
+    Z.p[i] = zero_ptrs_host[i];
+    Z.n[i] = (unsigned int)zero_counts_host[i];
+  }
+  Z.count = n_zero;
+  return ghost_clip_launch(n_layers, a_host, g_host, in_dim_host, out_dim_host, kind_host, B, dtype, max_norm, scale,
+                           scale_g_inplace, coef, norms, sq, Z, stream);
 }
 
 extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float* coef, int B,

@@ -686,6 +686,22 @@ class DPOptimizer:
         n = len(tapes)
         prescaled = False
         same_dtype = all(t.g.dtype == tapes[0].g.dtype for t in tapes)
+
+        def zero_list(prescaled_):
+            # Sums that are built with atomic adds (the affine sums; a Linear whose bf16 sum is split over
+            # the batch) start from zero
+            out = []
+            for t in tapes:
+                m = t.module
+                if t.kind != "linear":
+                    out += [self._slice(S, m.weight), self._slice(S, m.bias)]
+                elif t.g.dtype == torch.bfloat16 and not (
+                        prescaled_ and t.a.dtype == torch.bfloat16 and
+                        ops.gemm_bf16_supported(t.g.stride(0), True, t.a.shape[1], True, t.g.shape[1], t.a.shape[1], B)):
+                    out += [self._slice(S, m.weight)] + ([self._slice(S, m.bias)] if m.bias is not None else [])
+            return out
+
+        pre_zeroed = False
         if n <= 8 and same_dtype:
             import ctypes
             pa = (ctypes.c_void_p * n)(*[ptr(t.a) for t in tapes])
@@ -697,10 +713,16 @@ class DPOptimizer:
                                         for t in tapes])
             # the same launch scales every recorded backprop row by its clip coefficient in place
             # (the tapes are dead after this step), so the sums below are plain contractions
-            check(lib.vqaf_ghost_clip(n, pa, pg, din, dout, kind, B, dtype_code(tapes[0].g),
-                                      max_norm, scale, 1, ptr(coef), ptr(norms), None, st),
-                  "vqaf_ghost_clip")
+            # ... and clears the slices that the sums below build with atomic adds
+            zero = zero_list(True)
+            nz = len(zero) if len(zero) <= 8 else 0
+            zp = (ctypes.c_void_p * max(nz, 1))(*[ptr(z) for z in zero[:nz]])
+            zn = (ctypes.c_size_t * max(nz, 1))(*[z.numel() for z in zero[:nz]])
+            check(lib.vqaf_ghost_clip_zero(n, pa, pg, din, dout, kind, B, dtype_code(tapes[0].g),
+                                           max_norm, scale, 1, ptr(coef), ptr(norms), None, zp, zn, nz, st),
+                  "vqaf_ghost_clip_zero")
             prescaled = True
+            pre_zeroed = nz > 0
         else:
             sq = torch.empty(B, dtype=torch.float32, device=dev)
             for i, t in enumerate(tapes):
@@ -716,23 +738,15 @@ class DPOptimizer:
             check(lib.vqaf_clip_coef(ptr(sq), B, max_norm, scale, ptr(coef), ptr(norms), st),
                   "vqaf_clip_coef")
         self.last_norms, self._last_coef, self._last_scale = norms, coef, scale
-        # Sums that are built with atomic adds (the affine sums; a Linear whose bf16 sum is split over
-        # the batch) start from zero: one launch zeroes all their slices, instead of a memset each.
-        zero = []
-        for t in tapes:
-            m = t.module
-            if t.kind != "linear":
-                zero += [self._slice(S, m.weight), self._slice(S, m.bias)]
-            elif t.g.dtype == torch.bfloat16 and not (
-                    prescaled and t.a.dtype == torch.bfloat16 and
-                    ops.gemm_bf16_supported(t.g.stride(0), True, t.a.shape[1], True, t.g.shape[1], t.a.shape[1], B)):
-                zero += [self._slice(S, m.weight)] + ([self._slice(S, m.bias)] if m.bias is not None else [])
-        pre_zeroed = 0 < len(zero) <= 8
-        if pre_zeroed:
-            import ctypes
-            zp = (ctypes.c_void_p * len(zero))(*[ptr(z) for z in zero])
-            zn = (ctypes.c_size_t * len(zero))(*[z.numel() for z in zero])
-            check(lib.vqaf_zero_multi(zp, zn, len(zero), st), "vqaf_zero_multi")
+        if not pre_zeroed:
+            # one launch zeroes all those slices, instead of a memset each
+            zero = zero_list(prescaled)
+            pre_zeroed = 0 < len(zero) <= 8
+            if pre_zeroed:
+                import ctypes
+                zp = (ctypes.c_void_p * len(zero))(*[ptr(z) for z in zero])
+                zn = (ctypes.c_size_t * len(zero))(*[z.numel() for z in zero])
+                check(lib.vqaf_zero_multi(zp, zn, len(zero), st), "vqaf_zero_multi")
         acc = 1 if pre_zeroed else 0
         # the wide Linear layers' sums (S = G^T A, column sums of G) share ONE launch when each fills the chip
         grouped = []
