@@ -402,6 +402,35 @@ int vqaf_gemm_bf16(const void* A, long lda, int a_kmajor, const void* B, long ld
                    int K, const void* bias, int bias_dtype, void* C, long ldc, int c_dtype, int accumulate,
                    float* colsum, vqaf_stream_t stream);
 
+/* The clipped sums of n <= 4 Linear layers AND the DP step's update of their parameters in ONE launch
+ * (Opacus clip_and_accumulate + add_noise + scale_grad + the wrapped AdamW's step, train.py:130-153,
+ * utils/src.py:104): each 64 x 64 tile of S_W = G^T A (G (B,Out), A (B,In) bf16, rows already scaled by the
+ * clip factor) goes through noise, scaling and AdamW in registers and is never written; the tiles of the
+ * first column also update the bias from the row sums of G.  param / exp_avg / exp_avg_sq / grad_out (f32)
+ * and shadow_bf16 are the FLAT buckets of vqaf_dp_adamw; w_off[i] / b_off[i] are the element offsets of
+ * layer i's weight (Out_i x In_i, dense) and bias (b_off < 0: none) in them.  Element e of the buckets draws
+ * value (e - noise_lo) & 3 of generator call (e - noise_lo) >> 2 of rng_state {seed, counter}: the values
+ * one vqaf_dp_adamw launch over [noise_lo, ...) would draw, so updating some layers here and the rest with
+ * vqaf_dp_adamw_ranges equals that launch bit for bit.  `step` {unused, updates applied} is read, not
+ * advanced.  VQAF_E_SHAPE when the launch would have fewer than 192 tiles or a product wants 128-row tiles
+ * (use vqaf_gemm_bf16_wgrad_group + vqaf_dp_adamw); In_i a multiple of 8, offsets multiples of 4. */
+int vqaf_clipped_sum_adamw_group(int n, const void* const* G, const long* ldg, const void* const* A,
+                                 const long* lda, const int* Out, const int* In, int B, const long* w_off,
+                                 const long* b_off, long noise_lo, const uint64_t* rng_state, float noise_std,
+                                 float scale, float* param, float* exp_avg, float* exp_avg_sq,
+                                 void* shadow_bf16, float* grad_out, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, const uint64_t* step, vqaf_stream_t stream);
+
+/* vqaf_dp_adamw over n_ranges <= 8 ranges [offset, offset + count) of the flat buckets in one launch, S
+ * (the clipped sums) addressed by the same offsets, noise addressed as described above (offsets are
+ * multiples of 4 past noise_lo).  The parameters that vqaf_clipped_sum_adamw_group does not reach
+ * (normalisation layers) take this call. */
+int vqaf_dp_adamw_ranges(int n_ranges, const long* offsets_host, const size_t* counts_host, const float* S,
+                         const uint64_t* rng_state, long noise_lo, float noise_std, float scale, float* param,
+                         float* exp_avg, float* exp_avg_sq, void* shadow_bf16, float* grad_out, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, const uint64_t* step,
+                         vqaf_stream_t stream);
+
 /* Linear -> GroupNorm (-> ReLU -> Dropout) of the DP classifier (model/model.py:55-58 after
  * ModuleValidator.fix, train.py:124) in ONE launch: the normalisation runs on the Linear's output tile
  * before it leaves the workgroup.  x (B,K) bf16 rows ldx apart, W (C,K) bf16 rows ldw apart, bias (C) or

@@ -801,3 +801,41 @@ def test_linear_groupnorm_in_one_launch_equals_the_two_launches(dev):
         for (a0, g0), (a1, g1) in zip(t0, t1):
             assert a0.shape == a1.shape and g0.shape == g1.shape
             assert torch.equal(a0, a1) and torch.equal(g0, g1), kind
+
+
+def test_update_fused_into_the_clipped_sums_equals_the_separate_launches(dev):
+    """The Linear layers' clipped sums with the noise + AdamW update as their epilogue (and the normalisation
+    layers' update as one launch over their ranges) against the clipped-sum launch followed by the
+    whole-bucket update: parameters, moments, final gradients and the bf16 copy identical bit for bit over
+    several steps with in-kernel noise (the same generator addressing), at the classifier's shapes and at a
+    ragged one; the step count moves once per step."""
+    from vqa_amd import dp, ops
+    for in_dim, hidden, C, B in ((1024, 2048, 430, 64), (256, 512, 100, 40)):
+        x = gi.normal(1, B, in_dim).to(dev).bfloat16()
+        y = gi.labels(2, B, C).to(dev)
+        runs = []
+        for fuse in (False, True):
+            torch.manual_seed(3)
+            m = _classifier(77, in_dim, hidden, C).to(dev).train()
+            gsm = dp.GradSampleModule(m)
+            inner = torch.optim.AdamW(m.parameters(), lr=3e-3, weight_decay=0.05, betas=(0.9, 0.95), eps=1e-7)
+            opt = dp.DPOptimizer(inner, gsm, noise_multiplier=0.7, max_grad_norm=1.0, expected_batch_size=B, seed=11)
+            opt.fuse_update_into_sums = fuse
+            used = []
+            for step in range(3):
+                loss = ops.cross_entropy_mean(gsm(x), y)
+                loss.backward(gradient=ops.unit_gradient(loss))
+                opt.local_step()
+                used.append(bool(opt._updated))
+                opt.reduce_step()
+                opt.apply_step()
+            assert all(used) == fuse and any(used) == fuse
+            assert int(opt._step[1].item()) == 3
+            spans = [(opt._offsets[id(p)], p.numel()) for p in opt.params]
+            runs.append((opt._P.clone(), opt._M.clone(), opt._V.clone(), opt._grad.clone(), opt._shadow.clone()))
+        # every parameter's slice (the padding between slices belongs to no parameter: the whole-bucket launch
+        # updates it too, the fused one does not)
+        for a, b in zip(*runs):
+            for o, n in spans:
+                assert torch.equal(a[o:o + n], b[o:o + n])
+        assert float(runs[0][0].abs().sum()) > 0 and float(runs[0][3].abs().sum()) > 0

@@ -111,6 +111,10 @@ SIGNATURES = {
                                      _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
                                      c_float, c_int, _P]),
     "vqaf_gemm_bf16_supported": (c_int, [c_long, c_int, c_long, c_int, c_int, c_int, c_int]),
+    "vqaf_clipped_sum_adamw_group": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_long, _P, c_float, c_float,
+                                             _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),
+    "vqaf_dp_adamw_ranges": (c_int, [c_int, _P, _P, _P, _P, c_long, c_float, c_float, _P, _P, _P, _P, _P, c_float,
+                                     c_float, c_float, c_float, c_float, _P, _P]),
     "vqaf_linear_groupnorm_supported": (c_int, [c_long, c_long, c_int, c_int, c_int, c_int]),
     "vqaf_linear_dgrad_groupnorm_supported": (c_int, [c_long, c_long, c_int, c_int, c_int, c_int]),
     "vqaf_linear_dgrad_groupnorm_bwd": (c_int, [_P, c_long, _P, c_long, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int,

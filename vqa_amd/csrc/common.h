@@ -222,6 +222,38 @@ __device__ __forceinline__ void vqaf_normal4(unsigned long long seed, unsigned l
   vqaf_box_muller(r.x, r.y, z[0], z[1]);
   vqaf_box_muller(r.z, r.w, z[2], z[3]);
 }
+// One AdamW update of the DP step (torch.optim.AdamW's arithmetic on g = (S + noise_std z) scale), with
+// every operation pinned so that the kernels which share it produce the same bits.
+struct VqafAdamConsts {
+  float noise_std, scale, decay, one_m_b1, beta2, one_m_b2, bc2_sqrt, step_size, eps;
+};
+__device__ __forceinline__ VqafAdamConsts vqaf_adam_consts(unsigned long long steps_taken, float noise_std, float scale,
+                                                           float lr, float beta1, float beta2, float eps,
+                                                           float weight_decay) {
+  const float t = (float)(steps_taken + 1ull);
+  const float bc1 = 1.f - powf(beta1, t);
+  VqafAdamConsts c;
+  c.noise_std = noise_std;
+  c.scale = scale;
+  c.decay = 1.f - lr * weight_decay;
+  c.one_m_b1 = 1.f - beta1;
+  c.beta2 = beta2;
+  c.one_m_b2 = 1.f - beta2;
+  c.bc2_sqrt = sqrtf(1.f - powf(beta2, t));
+  c.step_size = lr / bc1;
+  c.eps = eps;
+  return c;
+}
+__device__ __forceinline__ void vqaf_adamw1(const VqafAdamConsts& c, float s, float z, float& p, float& m, float& v,
+                                            float& g) {
+  g = __fmul_rn(fmaf(c.noise_std, z, s), c.scale);
+  p = __fmul_rn(p, c.decay);
+  m = fmaf(c.one_m_b1, __fsub_rn(g, m), m);                        // lerp, as torch
+  v = fmaf(__fmul_rn(c.one_m_b2, g), g, __fmul_rn(c.beta2, v));
+  const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), c.bc2_sqrt), c.eps);
+  p = fmaf(-c.step_size, __fdiv_rn(m, denom), p);
+}
+
 // In-kernel counter bump for a FOUR-word generator state {seed, counter, ticket, reserved}: every
 // workgroup calls this once, after its last read of the state; the last one to arrive adds `delta`
 // to the counter and clears the ticket (which starts at zero and is zero between launches).  Saves the

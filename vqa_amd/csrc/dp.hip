@@ -756,11 +756,7 @@ dp_adamw_kernel(const float* __restrict__ S, const float* __restrict__ noise,
     seed = rng_state[0];
     counter = rng_state[1];
   }
-  const float t = (float)(step[1] + 1ull);
-  const float bc1 = 1.f - powf(beta1, t);
-  const float bc2_sqrt = sqrtf(1.f - powf(beta2, t));
-  const float step_size = lr / bc1;
-  const float decay = 1.f - lr * weight_decay;
+  const VqafAdamConsts ac = vqaf_adam_consts(step[1], noise_std, scale, lr, beta1, beta2, eps, weight_decay);
   const size_t ncall = (n + 3) >> 2;
   for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncall;
        c += (size_t)gridDim.x * blockDim.x) {
@@ -794,15 +790,7 @@ dp_adamw_kernel(const float* __restrict__ S, const float* __restrict__ noise,
     }
     float gv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float g = (sv[j] + noise_std * z[j]) * scale;
-      gv[j] = g;
-      pv[j] *= decay;
-      mv[j] = mv[j] + (1.f - beta1) * (g - mv[j]);           // lerp, as torch
-      vv[j] = beta2 * vv[j] + (1.f - beta2) * g * g;
-      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
-      pv[j] -= step_size * (mv[j] / denom);
-    }
+    for (int j = 0; j < 4; ++j) vqaf_adamw1(ac, sv[j], z[j], pv[j], mv[j], vv[j], gv[j]);
     if (cnt == 4) {
       // parameters, moments and gradient are next touched one whole step later: streaming stores
       // keep them from displacing (and dirtying) the caches the next forward reads through
@@ -825,6 +813,46 @@ dp_adamw_kernel(const float* __restrict__ S, const float* __restrict__ noise,
   }
   // `step` (which may also be the noise state) was read before the loop by every thread
   if (advance != 0) vqaf_rng_bump_by_last_workgroup(step, (unsigned long long)advance, gridDim.x);
+}
+
+// The same update over up to eight RANGES of the flat buckets in one launch (blockIdx.y picks the range).
+// Element i of the buckets draws value (i - noise_lo) & 3 of generator call (i - noise_lo) >> 2: the
+// addressing of one dp_adamw_kernel launch over [noise_lo, ...), whichever launch updates the element.
+constexpr int DA_MAX_RANGES = 8;
+struct AdamRanges {
+  long off[DA_MAX_RANGES];            // first element (a multiple of 4 past noise_lo)
+  unsigned int n[DA_MAX_RANGES];      // elements
+  int count;
+};
+__global__ void __launch_bounds__(DP_THREADS)
+dp_adamw_ranges_kernel(AdamRanges R, const float* __restrict__ S, const uint64_t* rng_state, long noise_lo,
+                       float noise_std, float scale, float* __restrict__ param, float* __restrict__ exp_avg,
+                       float* __restrict__ exp_avg_sq, bf16_t* __restrict__ shadow, float* __restrict__ grad_out,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, const uint64_t* step) {
+  long off = 0;
+  unsigned int n = 0;
+#pragma unroll
+  for (int i = 0; i < DA_MAX_RANGES; ++i)
+    if (i == (int)blockIdx.y) { off = R.off[i]; n = R.n[i]; }
+  const bool draw = noise_std != 0.f;
+  const unsigned long long seed = draw ? rng_state[0] : 0ull, counter = draw ? rng_state[1] : 0ull;
+  const VqafAdamConsts ac = vqaf_adam_consts(step[1], noise_std, scale, lr, beta1, beta2, eps, weight_decay);
+  const unsigned int ncall = (n + 3) >> 2;
+  for (unsigned int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncall; c += gridDim.x * blockDim.x) {
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    const long i0 = off + ((long)c << 2);
+    if (draw) vqaf_normal4(seed, counter, (unsigned long long)((i0 - noise_lo) >> 2), z);
+    const int cnt = min(4, (int)(n - (c << 2)));
+    for (int j = 0; j < cnt; ++j) {
+      float p = param[i0 + j], m = exp_avg[i0 + j], v = exp_avg_sq[i0 + j], g;
+      vqaf_adamw1(ac, S[i0 + j], z[j], p, m, v, g);
+      param[i0 + j] = p;
+      exp_avg[i0 + j] = m;
+      exp_avg_sq[i0 + j] = v;
+      if (grad_out != nullptr) grad_out[i0 + j] = g;
+      if (shadow != nullptr) shadow[i0 + j] = f32_to_bf16(p);
+    }
+  }
 }
 
 // GroupNorm on (B,C): one workgroup per sample, a lane owns 8 consecutive channels, a group of
@@ -1402,6 +1430,33 @@ extern "C" int vqaf_dp_adamw(const float* S, const float* noise, const uint64_t*
                      S, noise, rng_state, noise_std, scale, param, exp_avg, exp_avg_sq,
                      reinterpret_cast<bf16_t*>(shadow_bf16), grad_out, n, lr, beta1, beta2, eps,
                      weight_decay, step, step_advance);
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_dp_adamw_ranges(int n_ranges, const long* offsets_host, const size_t* counts_host, const float* S,
+                                    const uint64_t* rng_state, long noise_lo, float noise_std, float scale,
+                                    float* param, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                                    float* grad_out, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, const uint64_t* step, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(offsets_host && counts_host && S && param && exp_avg && exp_avg_sq && step, VQAF_E_NULL);
+  VQAF_REQUIRE(n_ranges > 0 && n_ranges <= DA_MAX_RANGES, VQAF_E_SHAPE);
+  VQAF_REQUIRE(noise_std == 0.f || rng_state != nullptr, VQAF_E_NULL);
+  AdamRanges R = {};
+  size_t longest = 0;
+  for (int i = 0; i < n_ranges; ++i) {
+    VQAF_REQUIRE(offsets_host[i] >= noise_lo && (offsets_host[i] - noise_lo) % 4 == 0, VQAF_E_ALIGN);
+    VQAF_REQUIRE(counts_host[i] > 0 && counts_host[i] < (1ull << 31), VQAF_E_SHAPE);
+    R.off[i] = offsets_host[i];
+    R.n[i] = (unsigned int)counts_host[i];
+    longest = counts_host[i] > longest ? counts_host[i] : longest;
+  }
+  R.count = n_ranges;
+  size_t blocks = ((longest + 3) / 4 + DP_THREADS - 1) / DP_THREADS;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(dp_adamw_ranges_kernel, dim3((unsigned)blocks, n_ranges), dim3(DP_THREADS), 0, (hipStream_t)stream,
+                     R, S, rng_state, noise_lo, noise_std, scale, param, exp_avg, exp_avg_sq,
+                     reinterpret_cast<bf16_t*>(shadow_bf16), grad_out, lr, beta1, beta2, eps, weight_decay, step);
   VQAF_LAUNCH_CHECK();
 }
 

@@ -72,6 +72,20 @@ struct GnEpi {
   float out_scale;      // 1 / (1 - p) of the inverted dropout, 1 without it
 };
 
+// The DP step's parameter update applied to a clipped-sum tile before it leaves the workgroup: the tile IS
+// the clipped gradient sum of 64 x 64 weights, so noise, scaling and AdamW run on it in registers and the
+// sum itself is never written.  Flat buckets as DPOptimizer keeps them (one offset per parameter).
+constexpr int GB_MAX_GROUP = 4;
+struct AdamEpi {
+  float* P; float* M; float* V; float* G;  // parameters, moments, final gradient (G may be NULL)
+  bf16_t* shadow;                          // bf16 copy of the parameters, or NULL
+  const uint64_t* rng;                     // {seed, counter} of the noise stream
+  const uint64_t* step;                    // {unused, updates applied}
+  float noise_std, scale, lr, beta1, beta2, eps, weight_decay;
+  long noise_lo;                           // flat index of element 0 of the noise stream
+  long w_off[GB_MAX_GROUP], b_off[GB_MAX_GROUP];  // flat offsets of each product's weight / bias (b_off < 0: none)
+};
+
 __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -115,7 +129,8 @@ __device__ __forceinline__ int rswz(int r) { return (r >> 1) & 7; }
 
 template <int MT, bool A_KMAJOR, bool B_KMAJOR, bool COLSUM, int STAGES = GB_STAGES, int EPI = 0>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile_m, const int tile_n,
-                                               const GnEpi* epi = nullptr) {
+                                               const GnEpi* epi = nullptr, const AdamEpi* adam = nullptr,
+                                               const long adam_w_off = 0, const long adam_b_off = -1) {
   constexpr int BM = 64 * MT;
   constexpr int A_BYTES = BM * GB_BK * 2;
   constexpr int B_BYTES = GB_BN * GB_BK * 2;
@@ -357,6 +372,94 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, const int tile
   if (g.bias != nullptr && n < g.N)
     bias_v = g.bias_bf16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(g.bias)[n])
                          : reinterpret_cast<const float*>(g.bias)[n];
+  if constexpr (EPI == 3) {
+    // AdamW epilogue of a clipped-sum tile (see AdamEpi).  The tile goes through LDS so that a thread owns
+    // 8 consecutive weights of a row: two generator calls, 16-byte moves of parameters and moments.
+    static_assert(MT == 1 && A_KMAJOR && B_KMAJOR, "AdamW epilogue: clipped-sum tiles of 64 x 64");
+    constexpr int TP = 68;
+    float* T = reinterpret_cast<float*>(gb_lds);
+    float* Tb = T + 64 * TP;  // the tile's 64 row sums (bias gradients)
+    const AdamEpi& e = *adam;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      T[row * TP + wn * 32 + (lane & 31)] = acc[0][r];
+      if (COLSUM && wn == 0 && (lane & 31) == 0) Tb[row] = csum[0][r];
+    }
+    __syncthreads();
+    const bool draw = e.noise_std != 0.f;
+    const unsigned long long seed = draw ? e.rng[0] : 0ull, counter = draw ? e.rng[1] : 0ull;
+    const VqafAdamConsts ac = vqaf_adam_consts(e.step[1], e.noise_std, e.scale, e.lr, e.beta1, e.beta2, e.eps, e.weight_decay);
+    const int chunk = tid & 7, nn = n0 + 8 * chunk;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = (tid >> 3) + 32 * pass, m = m0 + row;
+      if (m < g.M && nn < g.N) {
+        const long flat = adam_w_off + (long)m * g.N + nn;
+        float sv[8], z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * TP + 8 * chunk);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * TP + 8 * chunk + 4);
+        sv[0] = t0[0]; sv[1] = t0[1]; sv[2] = t0[2]; sv[3] = t0[3];
+        sv[4] = t1[0]; sv[5] = t1[1]; sv[6] = t1[2]; sv[7] = t1[3];
+        if (draw) {
+          float za[4], zb[4];
+          const unsigned long long call = (unsigned long long)((flat - e.noise_lo) >> 2);
+          vqaf_normal4(seed, counter, call, za);
+          vqaf_normal4(seed, counter, call + 1ull, zb);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { z[j] = za[j]; z[4 + j] = zb[j]; }
+        }
+        float pv[8], mv[8], vv[8], gv[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          // (requesting these before the k loop was measured: 48 more registers, two workgroups per CU
+          // instead of three, 68 instead of 56 us)
+          const f32x4 p4 = *reinterpret_cast<const f32x4*>(e.P + flat + 4 * h);
+          const f32x4 m4 = *reinterpret_cast<const f32x4*>(e.M + flat + 4 * h);
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(e.V + flat + 4 * h);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { pv[4 * h + j] = p4[j]; mv[4 * h + j] = m4[j]; vv[4 * h + j] = v4[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vqaf_adamw1(ac, sv[j], z[j], pv[j], mv[j], vv[j], gv[j]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          // next touched one whole step later: streamed past the caches, as the stand-alone update does
+          store_nt16(e.P + flat + 4 * h, u32x4{__float_as_uint(pv[4 * h]), __float_as_uint(pv[4 * h + 1]), __float_as_uint(pv[4 * h + 2]), __float_as_uint(pv[4 * h + 3])});
+          store_nt16(e.M + flat + 4 * h, u32x4{__float_as_uint(mv[4 * h]), __float_as_uint(mv[4 * h + 1]), __float_as_uint(mv[4 * h + 2]), __float_as_uint(mv[4 * h + 3])});
+          store_nt16(e.V + flat + 4 * h, u32x4{__float_as_uint(vv[4 * h]), __float_as_uint(vv[4 * h + 1]), __float_as_uint(vv[4 * h + 2]), __float_as_uint(vv[4 * h + 3])});
+          if (e.G != nullptr)
+            store_nt16(e.G + flat + 4 * h, u32x4{__float_as_uint(gv[4 * h]), __float_as_uint(gv[4 * h + 1]), __float_as_uint(gv[4 * h + 2]), __float_as_uint(gv[4 * h + 3])});
+        }
+        if (e.shadow != nullptr) {  // (bucket offsets are multiples of 4 elements: 8-byte pieces of the bf16 copy)
+          *reinterpret_cast<u32x2*>(e.shadow + flat) = u32x2{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+          *reinterpret_cast<u32x2*>(e.shadow + flat + 4) = u32x2{pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])};
+        }
+      }
+    }
+    if constexpr (COLSUM) {
+      const int m = m0 + tid;
+      if (tid < 64 && m < g.M && adam_b_off >= 0) {  // the bias of output row m: its gradient sum is the row sum of G
+        const long flat = adam_b_off + m, idx = flat - e.noise_lo;
+        float z = 0.f;
+        if (draw) {
+          float z4[4];
+          vqaf_normal4(seed, counter, (unsigned long long)(idx >> 2), z4);
+          const int j = (int)(idx & 3);
+          z = j == 0 ? z4[0] : j == 1 ? z4[1] : j == 2 ? z4[2] : z4[3];
+        }
+        float p = e.P[flat], mo = e.M[flat], v = e.V[flat], gg;
+        vqaf_adamw1(ac, Tb[tid], z, p, mo, v, gg);
+        e.P[flat] = p;
+        e.M[flat] = mo;
+        e.V[flat] = v;
+        if (e.G != nullptr) e.G[flat] = gg;
+        if (e.shadow != nullptr) e.shadow[flat] = f32_to_bf16(p);
+      }
+    }
+    return;
+  }
   if constexpr (EPI == 1) {
     // GroupNorm epilogue (64 x 64 tile, N a multiple of 64, 8 <= group size <= 64 dividing 64).  The tile
     // goes through LDS (the operand ring is free now; the fetching waves have left) so that a thread owns 8
@@ -533,7 +636,6 @@ gemm_bf16_gn_bwd_kernel(GemmArgs g, GnEpi e) {
 // Several weight-gradient-shaped products (both operands k-major, the same contraction length) in ONE
 // launch: the clipped sums of the classifier's Linear layers are a few hundred tiles and sixteen k-steps
 // each, so a launch of their own costs each of them as much as its arithmetic.
-constexpr int GB_MAX_GROUP = 4;
 constexpr int GB_GROUP_STAGES = 3;  // 72 KiB per workgroup: two workgroups (of different products) share a CU
 struct GemmGroup {
   GemmArgs p[GB_MAX_GROUP];
@@ -559,6 +661,26 @@ gemm_bf16_wgrad_group_kernel(GemmGroup G) {
   tile_of(g, id - base, tile_m, tile_n);
   if (g.colsum != nullptr && tile_n == 0) gemm_bf16_body<MT, true, true, true, GB_GROUP_STAGES>(g, tile_m, tile_n);
   else gemm_bf16_body<MT, true, true, false, GB_GROUP_STAGES>(g, tile_m, tile_n);
+}
+
+// The grouped clipped sums with the AdamW epilogue (64 x 64 tiles).
+__global__ void __launch_bounds__(2 * GB_THREADS)
+gemm_bf16_wgrad_adamw_kernel(GemmGroup G, AdamEpi E) {
+  const int id = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GB_MAX_GROUP; ++i)
+    if (i < G.n && id >= G.first[i]) pi = i;
+  GemmArgs g = G.p[0];
+  int base = G.first[0];
+  long w_off = E.w_off[0], b_off = E.b_off[0];
+  if (pi == 1) { g = G.p[1]; base = G.first[1]; w_off = E.w_off[1]; b_off = E.b_off[1]; }
+  if (pi == 2) { g = G.p[2]; base = G.first[2]; w_off = E.w_off[2]; b_off = E.b_off[2]; }
+  if (pi == 3) { g = G.p[3]; base = G.first[3]; w_off = E.w_off[3]; b_off = E.b_off[3]; }
+  int tile_m, tile_n;
+  tile_of(g, id - base, tile_m, tile_n);
+  if (b_off >= 0 && tile_n == 0) gemm_bf16_body<1, true, true, true, GB_GROUP_STAGES, 3>(g, tile_m, tile_n, nullptr, &E, w_off, b_off);
+  else gemm_bf16_body<1, true, true, false, GB_GROUP_STAGES, 3>(g, tile_m, tile_n, nullptr, &E, w_off, -1);
 }
 
 constexpr int GB_MAX_DEVICES = 64;
@@ -767,6 +889,74 @@ long plan_wgrad(GemmArgs& g, int& MT, int M, int N, int K) {
   return (long)g.tiles_m * g.tiles_n;
 }
 }  // namespace
+
+extern "C" int vqaf_clipped_sum_adamw_group(int n, const void* const* Gp, const long* ldg, const void* const* Ap,
+                                            const long* lda, const int* Out, const int* In, int B,
+                                            const long* w_off, const long* b_off, long noise_lo,
+                                            const uint64_t* rng_state, float noise_std, float scale, float* param,
+                                            float* exp_avg, float* exp_avg_sq, void* shadow_bf16, float* grad_out,
+                                            float lr, float beta1, float beta2, float eps, float weight_decay,
+                                            const uint64_t* step, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(Gp && ldg && Ap && lda && Out && In && w_off && b_off && param && exp_avg && exp_avg_sq && step, VQAF_E_NULL);
+  VQAF_REQUIRE(n >= 1 && n <= GB_MAX_GROUP && B > 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(noise_std == 0.f || rng_state != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_aligned16(param) && vqaf_aligned16(exp_avg) && vqaf_aligned16(exp_avg_sq) &&
+                   (grad_out == nullptr || vqaf_aligned16(grad_out)) &&
+                   (shadow_bf16 == nullptr || vqaf_aligned16(shadow_bf16)), VQAF_E_ALIGN);
+  const unsigned int* zeros = nullptr;
+  const int rc = zero_block_on_current_device(&zeros);
+  if (rc != VQAF_OK) return rc;
+  GemmGroup G;
+  G.n = n;
+  AdamEpi E = {};
+  int next = 0;
+  long total_tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    VQAF_REQUIRE(Gp[i] && Ap[i], VQAF_E_NULL);
+    VQAF_REQUIRE(Out[i] > 0 && In[i] > 0 && In[i] % 8 == 0, VQAF_E_SHAPE);
+    VQAF_REQUIRE(vqaf_gemm_bf16_supported(ldg[i], 1, lda[i], 1, Out[i], In[i], B), VQAF_E_ALIGN);
+    VQAF_REQUIRE(vqaf_aligned16(Gp[i]) && vqaf_aligned16(Ap[i]), VQAF_E_ALIGN);
+    // eight consecutive weights of a row are one 32-byte piece of the buckets and two whole generator calls
+    VQAF_REQUIRE(w_off[i] >= noise_lo && (w_off[i] - noise_lo) % 4 == 0 && w_off[i] % 4 == 0, VQAF_E_ALIGN);
+    VQAF_REQUIRE(b_off[i] < 0 || b_off[i] >= noise_lo, VQAF_E_SHAPE);
+    GemmArgs& g = G.p[i];
+    int MT = 1;
+    total_tiles += plan_wgrad(g, MT, Out[i], In[i], B);
+    VQAF_REQUIRE(MT == 1, VQAF_E_SHAPE);  // the epilogue is written for 64 x 64 tiles
+    g.A = reinterpret_cast<const bf16_t*>(Gp[i]);
+    g.B = reinterpret_cast<const bf16_t*>(Ap[i]);
+    g.bias = nullptr;
+    g.bias_bf16 = 0;
+    g.C = nullptr;
+    g.colsum = nullptr;
+    g.zeros = zeros;
+    g.lda = ldg[i]; g.ldb = lda[i]; g.ldc = In[i];
+    g.out_mode = GB_OUT_F32;
+    G.first[i] = next;
+    next += g.tiles_m * g.tiles_n;
+    E.w_off[i] = w_off[i];
+    E.b_off[i] = b_off[i];
+  }
+  VQAF_REQUIRE(total_tiles >= 192, VQAF_E_SHAPE);
+  for (int i = n; i <= GB_MAX_GROUP; ++i) G.first[i] = next;
+  for (int i = n; i < GB_MAX_GROUP; ++i) { G.p[i] = G.p[0]; E.w_off[i] = E.w_off[0]; E.b_off[i] = -1; }
+  E.P = param; E.M = exp_avg; E.V = exp_avg_sq; E.G = grad_out;
+  E.shadow = reinterpret_cast<bf16_t*>(shadow_bf16);
+  E.rng = rng_state; E.step = step;
+  E.noise_std = noise_std; E.scale = scale; E.lr = lr; E.beta1 = beta1; E.beta2 = beta2; E.eps = eps;
+  E.weight_decay = weight_decay; E.noise_lo = noise_lo;
+  constexpr size_t smem = (size_t)GB_GROUP_STAGES * (64 + GB_BN) * GB_BK * 2;
+  static_assert(smem >= (64 * 68 + 64) * sizeof(float), "the staged tile and its row sums live in the operand ring");
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_wgrad_adamw_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  hipLaunchKernelGGL(gemm_bf16_wgrad_adamw_kernel, dim3((unsigned)next, 1, 1), dim3(2 * GB_THREADS), smem,
+                     (hipStream_t)stream, G, E);
+  VQAF_LAUNCH_CHECK();
+}
 
 extern "C" int vqaf_gemm_bf16_wgrad_group(int n, const void* const* A, const long* lda, const void* const* B,
                                           const long* ldb, const int* M, const int* N, int K, float* const* C,

@@ -478,6 +478,12 @@ class DPOptimizer:
         self._P = self._M = self._V = self._shadow = self._step = None
         self._pending_state = None  # optimizer state loaded before the fused buckets exist
         self._use_fused = False
+        # With one rank, in-kernel noise and one parameter group, the clipped-sum launch of the Linear layers
+        # can apply the update itself (vqaf_clipped_sum_adamw_group); _updated lists what it covered this
+        # step.  Off by default: the update's 130 MB of parameter and moment traffic is not hidden under the
+        # GEMM (56 + 7 us against 31 + 30 us for the two launches at batch 1024), so nothing is gained yet.
+        self.fuse_update_into_sums = False
+        self._updated = None
         self.last_norms = None
         self._last_coef, self._last_scale = None, 1.0
 
@@ -621,6 +627,29 @@ class DPOptimizer:
         else:
             src, std, scale, noise = grad, 0.0, 1.0, None
         single = len(self.original_optimizer.param_groups) == 1
+        if self._updated:
+            # the clipped-sum launch already updated the Linear layers: the rest (normalisation layers) in
+            # one launch over their ranges, with the noise addressing of the whole-bucket launch
+            if noise is not None:
+                raise RuntimeError("the update was fused into the clipped sums (in-kernel noise); call "
+                                   "clip_and_accumulate() without fuse_update to inject noise")
+            import ctypes
+            group, lo = self._single_group()
+            b1, b2 = group["betas"]
+            rest = [p for p in group["params"] if id(p) in self._offsets and id(p) not in self._updated]
+            for i in range(0, len(rest), 8):
+                part = rest[i:i + 8]
+                check(lib.vqaf_dp_adamw_ranges(
+                    len(part), (ctypes.c_long * len(part))(*[self._offsets[id(p)] for p in part]),
+                    (ctypes.c_size_t * len(part))(*[p.numel() for p in part]), ptr(S), ptr(self._step), lo, std, scale,
+                    ptr(self._P), ptr(self._M), ptr(self._V), ptr(self._shadow), ptr(grad), float(group["lr"]),
+                    float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), ptr(self._step), st),
+                    "vqaf_dp_adamw_ranges")
+            self._updated = None
+            check(lib.vqaf_rng_advance(ptr(self._step), 1, st), "vqaf_rng_advance")
+            self.module.step_counter = self._step
+            self.module._drop_calls = 0
+            return
         for group in self.original_optimizer.param_groups:
             ps = [p for p in group["params"] if id(p) in self._offsets]
             if not ps:
@@ -657,8 +686,11 @@ class DPOptimizer:
         return buf[o:o + p.numel()]
 
     @torch.no_grad()
-    def clip_and_accumulate(self):
-        """Fills the flat clipped-sum buffer from the layer tapes; returns it."""
+    def clip_and_accumulate(self, fuse_update: bool = False):
+        """Fills the flat clipped-sum buffer from the layer tapes; returns it.  With fuse_update the launch
+        that forms the Linear layers' sums also applies their noise + AdamW update (those slices of the
+        buffer are then not written; self._updated names the parameters)."""
+        self._updated = None
         tapes = [t for t in self.module.tapes if t.g is not None]
         if not tapes:
             raise RuntimeError("DPOptimizer.step() called before loss.backward()")
@@ -755,9 +787,13 @@ class DPOptimizer:
                     t.a.dtype == torch.bfloat16 and t.g.stride(1) == 1 and
                     ops.gemm_bf16_supported(t.g.stride(0), True, t.a.shape[1], True, t.g.shape[1], t.a.shape[1], B)]
             if 2 <= len(cand) <= 4:
+                probe = "clipped_sum_linear:" + "+".join(f"{t.g.shape[1]}x{t.a.shape[1]}" for t in cand)
+                if fuse_update and self._sums_with_update(cand, B, probe):
+                    grouped = cand
+                    self._updated = {id(p) for t in cand for p in (t.module.weight, t.module.bias) if p is not None}
+            if 2 <= len(cand) <= 4 and not grouped:
                 items = [(t.g, t.a, self._slice(S, t.module.weight).view(t.g.shape[1], t.a.shape[1]),
                           self._slice(S, t.module.bias) if t.module.bias is not None else None) for t in cand]
-                probe = "clipped_sum_linear:" + "+".join(f"{t.g.shape[1]}x{t.a.shape[1]}" for t in cand)
                 if ops.gemm_bf16_wgrad_group(items, B, name=probe):
                     grouped = cand
         # the affine (GroupNorm) layers' sums share one launch too when their slices are already zeroed
@@ -804,6 +840,42 @@ class DPOptimizer:
             t.g = None
         return S
 
+    def _single_group(self):
+        """(group, lo) when every private parameter sits in ONE group of the wrapped optimizer, else None."""
+        groups = [g for g in self.original_optimizer.param_groups if any(id(p) in self._offsets for p in g["params"])]
+        if len(self.original_optimizer.param_groups) != 1 or len(groups) != 1:
+            return None
+        return groups[0], min(self._offsets[id(p)] for p in groups[0]["params"] if id(p) in self._offsets)
+
+    def _sums_with_update(self, cand, B: int, probe: str) -> bool:
+        """The Linear layers' clipped sums and their noise + AdamW update in one launch; False (nothing
+        launched) when the shapes are not covered."""
+        import ctypes
+        sg = self._single_group()
+        if sg is None or any(id(t.module.weight) not in self._offsets or
+                             (t.module.bias is not None and id(t.module.bias) not in self._offsets) or
+                             t.a.shape[1] % 8 != 0 for t in cand):
+            return False
+        group, lo = sg
+        n = len(cand)
+        vp, lg, it = ctypes.c_void_p * n, ctypes.c_long * n, ctypes.c_int * n
+        b1, b2 = group["betas"]
+        ops._probe(probe, "begin")
+        status = load().vqaf_clipped_sum_adamw_group(
+            n, vp(*[t.g.data_ptr() for t in cand]), lg(*[t.g.stride(0) for t in cand]),
+            vp(*[t.a.data_ptr() for t in cand]), lg(*[t.a.stride(0) for t in cand]),
+            it(*[t.g.shape[1] for t in cand]), it(*[t.a.shape[1] for t in cand]), B,
+            lg(*[self._offsets[id(t.module.weight)] for t in cand]),
+            lg(*[self._offsets[id(t.module.bias)] if t.module.bias is not None else -1 for t in cand]), lo,
+            ptr(self._step), self.noise_multiplier * self.max_grad_norm, 1.0 / self.expected_batch_size,
+            ptr(self._P), ptr(self._M), ptr(self._V), ptr(self._shadow), ptr(self._grad), float(group["lr"]), float(b1),
+            float(b2), float(group["eps"]), float(group["weight_decay"]), ptr(self._step), stream_ptr(self._P.device))
+        ops._probe(probe, "end")
+        if status == -1:  # VQAF_E_SHAPE: too few tiles for one launch
+            return False
+        check(status, "vqaf_clipped_sum_adamw_group")
+        return True
+
     @torch.no_grad()
     def _noise_scale_local(self, noise: Optional[torch.Tensor] = None):
         """grad = (S + (sigma C / sqrt(world)) z) / expected_batch_size on this rank (no exchange)."""
@@ -832,9 +904,17 @@ class DPOptimizer:
     def local_step(self, noise: Optional[torch.Tensor] = None):
         """Per-rank work before the exchange: ghost norms, clip, clipped sums and -- unless the
         fused single-GPU kernel will add it -- this rank's noise share and the scaling."""
-        self.clip_and_accumulate()
         world, _ = self._world()
         self._use_fused = self._fusable() or self._P is not None
+        fuse_update = False
+        if self._use_fused and world == 1 and noise is None and self.fuse_update_into_sums and \
+                self._single_group() is not None and self.noise_multiplier * self.max_grad_norm >= 0.0:
+            tapes = [t for t in self.module.tapes if t.g is not None]
+            if tapes:
+                self._buffers(tapes[0].g.device)
+                self._fused_buffers(tapes[0].g.device)
+                fuse_update = True
+        self.clip_and_accumulate(fuse_update=fuse_update)
         if not (self._use_fused and world == 1):
             self._noise_scale_local(noise)
 
