@@ -82,7 +82,19 @@ class _SingleQueryTokens(torch.autograd.Function):
                                 ctx.needs_input_grad[1])
 
 
-def _gemm(A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha=1.0, bias=None, bias_sg=0):
+def _zeroed(dev, *shapes):
+    """f32 tensors of the given shapes carved out of ONE zero-filled allocation (one fill launch): outputs of
+    _gemm(..., into_zeros=True), which then adds into them instead of clearing each one with its own memset."""
+    sizes = [(math.prod(sh) + 3) // 4 * 4 for sh in shapes]  # 16-byte aligned pieces
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    out, o = [], 0
+    for sh, n in zip(shapes, sizes):
+        out.append(flat[o:o + math.prod(sh)].view(sh))
+        o += n
+    return out
+
+
+def _gemm(A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha=1.0, bias=None, bias_sg=0, into_zeros=False):
     """C[g][m][n] = alpha sum_k A[g][m][k] B[g][k][n] (+ bias[g][n]) through vqaf_gemm_f32_atomic.  A, Bm, C and
     bias are (tensor, element offset) pairs addressed by element strides a_s = (s_g, s_m, s_k),
     b_s = (s_g, s_k, s_n), c_s = (s_g, s_m); transposes and head slices cost nothing."""
@@ -99,7 +111,8 @@ def _gemm(A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha=1.0, bias=None, bias_sg=0):
     check(load().vqaf_gemm_f32_atomic(addr(A), code(at), a_s[0], a_s[1], a_s[2], addr(Bm), code(bt), b_s[0], b_s[1], b_s[2],
                                addr(bias) if bias is not None else None,
                                code(bias[0]) if bias is not None else _lib.F32, bias_sg, addr(C), c_s[0], c_s[1],
-                                      G, M, N, K, float(alpha), 0, stream_ptr(ct.device)), "vqaf_gemm_f32_atomic")
+                                      G, M, N, K, float(alpha), int(into_zeros), stream_ptr(ct.device)),
+          "vqaf_gemm_f32_atomic")
 
 
 class _DenseSingleQuery(torch.autograd.Function):
@@ -117,9 +130,7 @@ class _DenseSingleQuery(torch.autograd.Function):
         w_in_c, b_in_c, w_out_c, b_out_c = (t.detach().contiguous() for t in (w_in, b_in, w_out, b_out))
         if q_c.dtype not in (torch.float32, torch.bfloat16):
             q_c = q_c.float()
-        f32 = dict(dtype=torch.float32, device=dev)
-        qp = torch.empty(B, E, **f32)
-        u = torch.empty(B, H, E, **f32)
+        qp, u, attn, out = _zeroed(dev, (B, E), (B, H, E), (B, E), (B, E))
         if q_c.dtype == torch.bfloat16 and w_in_c.dtype == torch.bfloat16 and b_in_c.dtype == torch.bfloat16 \
                 and E == 512 and dh == 64:
             # both products in one launch on the bf16 matrix cores (f32-accurate: see vqaf_fold_query)
@@ -127,17 +138,17 @@ class _DenseSingleQuery(torch.autograd.Function):
                                          ptr(u), stream_ptr(dev)), "vqaf_fold_query")
         else:
             # qp = query Wq^T + bq
-            _gemm((q_c, 0), (0, E, 1), (w_in_c, 0), (0, 1, E), (qp, 0), (0, E), 1, B, E, E, bias=(b_in_c, 0))
+            _gemm((q_c, 0), (0, E, 1), (w_in_c, 0), (0, 1, E), (qp, 0), (0, E), 1, B, E, E, bias=(b_in_c, 0),
+                  into_zeros=True)
             # u[:,h,:] = qp[:, head h] Wk[head h, :] / sqrt(dh)
             _gemm((qp, 0), (dh, E, 1), (w_in_c, E * E), (dh * E, E, 1), (u, 0), (E, H * E), H, B, E, dh,
-                  alpha=1.0 / math.sqrt(dh))
+                  alpha=1.0 / math.sqrt(dh), into_zeros=True)
         z, p = _tokens_forward(seq_c, u)
         # attn[:, head h] = z[:,h,:] Wv[head h, :]^T + bv[head h]
-        attn = torch.empty(B, E, **f32)
         _gemm((z, 0), (E, H * E, 1), (w_in_c, 2 * E * E), (dh * E, 1, E), (attn, 0), (dh, E), H, B, dh, E,
-              bias=(b_in_c, 2 * E), bias_sg=dh)
-        out = torch.empty(B, E, **f32)
-        _gemm((attn, 0), (0, E, 1), (w_out_c, 0), (0, 1, E), (out, 0), (0, E), 1, B, E, E, bias=(b_out_c, 0))
+              bias=(b_in_c, 2 * E), bias_sg=dh, into_zeros=True)
+        _gemm((attn, 0), (0, E, 1), (w_out_c, 0), (0, 1, E), (out, 0), (0, E), 1, B, E, E, bias=(b_out_c, 0),
+              into_zeros=True)
         ctx.save_for_backward(q_c, seq_c, w_in_c, w_out_c, qp, u, p, z, attn)
         ctx.H = H
         ctx.dtypes = (query.dtype, w_in.dtype, b_in.dtype, w_out.dtype, b_out.dtype)
@@ -155,43 +166,47 @@ class _DenseSingleQuery(torch.autograd.Function):
         need_q, need_seq, need_win, need_bin, need_wout, need_bout = ctx.needs_input_grad[:6]
         g = g_out.contiguous().float()
         scale = 1.0 / math.sqrt(dh)
+        # every f32 output of the products below comes out of one zero-filled allocation (one fill launch
+        # instead of a memset per split product)
+        d_attn, d_wout, t, d_win, d_qp, d_q = _zeroed(dev, (B, E), (E, E), (B, H, E), (3 * E, E), (B, E), (B, E))
         # through the output projection
-        d_attn = torch.empty(B, E, **f32)
-        _gemm((g, 0), (0, E, 1), (w_out_c, 0), (0, E, 1), (d_attn, 0), (0, E), 1, B, E, E)
-        d_wout = d_bout = None
+        _gemm((g, 0), (0, E, 1), (w_out_c, 0), (0, E, 1), (d_attn, 0), (0, E), 1, B, E, E, into_zeros=True)
+        d_bout = None
         if need_wout:
-            d_wout = torch.empty(E, E, **f32)
-            _gemm((g, 0), (0, 1, E), (attn, 0), (0, E, 1), (d_wout, 0), (0, E), 1, E, E, B)
+            _gemm((g, 0), (0, 1, E), (attn, 0), (0, E, 1), (d_wout, 0), (0, E), 1, E, E, B, into_zeros=True)
+        else:
+            d_wout = None
         if need_bout:
             d_bout = g.sum(0)
         # through the value projection: t[:,h,:] = d_attn[:, head h] Wv[head h, :]
-        t = torch.empty(B, H, E, **f32)
-        _gemm((d_attn, 0), (dh, E, 1), (w_in_c, 2 * E * E), (dh * E, E, 1), (t, 0), (E, H * E), H, B, E, dh)
-        d_win = torch.empty(3 * E, E, **f32) if need_win else None
+        _gemm((d_attn, 0), (dh, E, 1), (w_in_c, 2 * E * E), (dh * E, E, 1), (t, 0), (E, H * E), H, B, E, dh,
+              into_zeros=True)
+        if not need_win:
+            d_win = None
         d_bin = torch.zeros(3 * E, **f32) if need_bin else None  # the key bias shifts every score of a head alike
         if need_win:  # dWv[head h rows] = d_attn[:, head h]^T z[:,h,:]
-            _gemm((d_attn, 0), (dh, 1, E), (z, 0), (E, H * E, 1), (d_win, 2 * E * E), (dh * E, E), H, dh, E, B)
+            _gemm((d_attn, 0), (dh, 1, E), (z, 0), (E, H * E, 1), (d_win, 2 * E * E), (dh * E, E), H, dh, E, B,
+                  into_zeros=True)
         if need_bin:
             torch.sum(d_attn, 0, out=d_bin[2 * E:])
         # through the token passes
         need_u = need_q or need_win or need_bin
         gseq, du = _tokens_backward(seq_c, u, p, t, need_seq, need_u)
-        d_q = None
         if need_u:
             # d_qp[:, head h] = du[:,h,:] Wk[head h, :]^T / sqrt(dh)
-            d_qp = torch.empty(B, E, **f32)
             _gemm((du, 0), (E, H * E, 1), (w_in_c, E * E), (dh * E, 1, E), (d_qp, 0), (dh, E), H, B, dh, E,
-                  alpha=scale)
+                  alpha=scale, into_zeros=True)
             if need_win:
                 # dWk[head h rows] = qp[:, head h]^T du[:,h,:] / sqrt(dh);  dWq = d_qp^T query
                 _gemm((qp, 0), (dh, 1, E), (du, 0), (E, H * E, 1), (d_win, E * E), (dh * E, E), H, dh, E, B,
-                      alpha=scale)
-                _gemm((d_qp, 0), (0, 1, E), (q_c, 0), (0, E, 1), (d_win, 0), (0, E), 1, E, E, B)
+                      alpha=scale, into_zeros=True)
+                _gemm((d_qp, 0), (0, 1, E), (q_c, 0), (0, E, 1), (d_win, 0), (0, E), 1, E, E, B, into_zeros=True)
             if need_bin:
                 torch.sum(d_qp, 0, out=d_bin[:E])
             if need_q:
-                d_q = torch.empty(B, E, **f32)
-                _gemm((d_qp, 0), (0, E, 1), (w_in_c, 0), (0, E, 1), (d_q, 0), (0, E), 1, B, E, E)
+                _gemm((d_qp, 0), (0, E, 1), (w_in_c, 0), (0, E, 1), (d_q, 0), (0, E), 1, B, E, E, into_zeros=True)
+        if not (need_u and need_q):
+            d_q = None
         qd, wid, bid, wod, bod = ctx.dtypes
         cast = lambda x, d: None if x is None else (x if x.dtype == d else x.to(d))  # noqa: E731
         return (cast(d_q.view(ctx.q_shape), qd) if d_q is not None else None, gseq, cast(d_win, wid),
