@@ -994,12 +994,13 @@ ce_conf_kernel(const void* __restrict__ logits, const int64_t* __restrict__ targ
                unsigned int* __restrict__ ticket) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (DP_THREADS / 64) + (threadIdx.x >> 6);
-  if (b < B) {
-    const bool cached = C <= 64 * CE_REG;
-    const int64_t t = targets != nullptr ? targets[b] : -1;  // requested first: nothing below waits on it alone
-    float v[CE_REG];
+  const bool row = b < B, cached = C <= 64 * CE_REG;
+  int64_t t = -1;
+  float v[CE_REG];
+  float m = -INFINITY, z = 0.f;
+  if (row) {
+    t = targets != nullptr ? targets[b] : -1;  // requested first: nothing below waits on it alone
     float xt = 0.f;  // the target's logit (cached rows: picked out of the registers)
-    float m = -INFINITY;
     int am = 0x7fffffff;  // lowest index wins among equal maxima
     if (cached) {
 #pragma unroll
@@ -1025,7 +1026,6 @@ ce_conf_kernel(const void* __restrict__ logits, const int64_t* __restrict__ targ
       const int oa = __shfl_xor(am, o, 64);
       if (om > m || (om == m && oa < am)) { m = om; am = oa; }
     }
-    float z = 0.f;
     if (cached) {
 #pragma unroll
       for (int i = 0; i < CE_REG; ++i) {
@@ -1044,30 +1044,34 @@ ce_conf_kernel(const void* __restrict__ logits, const int64_t* __restrict__ targ
       if (conf != nullptr) conf[b] = 1.0f / z;
       if (pred != nullptr) pred[b] = (int64_t)(am == 0x7fffffff ? 0 : am);
     }
-    if (grad_logits != nullptr) {
-      if (cached) {
-#pragma unroll
-        for (int i = 0; i < CE_REG; ++i) {
-          const int c = lane + 64 * i;
-          if (c < C) store1<GBF16>(grad_logits, (size_t)b * ldg + c, grad_scale * (v[i] / z - ((int64_t)c == t ? 1.f : 0.f)));
-        }
-      } else {
-        for (int c = lane; c < C; c += 64) {
-          const float p = expf(load1<BF16>(logits, (size_t)b * C + c) - m) / z;
-          store1<GBF16>(grad_logits, (size_t)b * ldg + c, grad_scale * (p - ((int64_t)c == t ? 1.f : 0.f)));
-        }
-      }
-      for (int c = C + lane; c < ldg; c += 64) store1<GBF16>(grad_logits, (size_t)b * ldg + c, 0.f);  // row padding
+  }
+  // The ticket is taken as soon as the workgroup's losses are written, BEFORE its gradient rows: the fence
+  // then waits for four floats, not for the rows, and the last workgroup adds up while rows are still landing.
+  __shared__ int s_last;
+  if (loss_mean != nullptr) {  // uniform
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
+    __syncthreads();
+  }
+  if (row && grad_logits != nullptr) {
+    if (cached) {
+#pragma unroll
+      for (int i = 0; i < CE_REG; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) store1<GBF16>(grad_logits, (size_t)b * ldg + c, grad_scale * (v[i] / z - ((int64_t)c == t ? 1.f : 0.f)));
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) {
+        const float p = expf(load1<BF16>(logits, (size_t)b * C + c) - m) / z;
+        store1<GBF16>(grad_logits, (size_t)b * ldg + c, grad_scale * (p - ((int64_t)c == t ? 1.f : 0.f)));
+      }
+    }
+    for (int c = C + lane; c < ldg; c += 64) store1<GBF16>(grad_logits, (size_t)b * ldg + c, 0.f);  // row padding
   }
   if (loss_mean == nullptr) return;  // uniform
-  __shared__ int s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
   if (s_last) {
     // thread t adds rows t, t + 256, ... (four requests in flight at a time), waves and threads are
     // combined in index order
