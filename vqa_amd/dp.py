@@ -224,8 +224,10 @@ class _GhostGroupNorm(torch.autograd.Function):
 class _GhostLinearGroupNorm(torch.autograd.Function):
     """Linear -> GroupNorm (-> ReLU -> Dropout) with the normalisation as the epilogue of the Linear's GEMM
     (vqaf_linear_groupnorm_fwd: one launch, the same bits as _GhostLinear followed by _GhostGroupNorm).
-    Backward: the GroupNorm backward kernel, then the Linear's input gradient; both layers' tapes are
-    filled as the separate functions fill them."""
+    Backward: the norm's backward has usually run already, as the epilogue of the consuming Linear's
+    input-gradient GEMM (link_out.done; see _GnLink), otherwise the GroupNorm backward kernel runs here; then
+    the Linear's input gradient, itself with the backward of the norm in FRONT of this block as its epilogue
+    when there is one (link_in).  Both layers' tapes are filled as the separate functions fill them."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, gn_weight, gn_bias, groups, eps, relu, lin_tape, gn_tape, drop_p=0.0,
