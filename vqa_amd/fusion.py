@@ -229,6 +229,24 @@ class Attention(nn.Module):
         return torch.cat([attended_v, q_global.to(attended_v.dtype)], dim=1)
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device):
+    """A second stream of `device` for the dense co-attention's second branch (module level: a module that
+    is copied or pickled never meets a stream object); None while a graph is being captured before the
+    stream exists (a stream cannot be created then)."""
+    if device.type != "cuda":
+        return None
+    st = _SIDE_STREAMS.get(device.index)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[device.index] = st
+    return st
+
+
 class CoAttention(nn.Module):
     """Co-attention with privacy-aware token pruning (utils/fusion.py:186-275)."""
 
@@ -243,6 +261,7 @@ class CoAttention(nn.Module):
         self.fuse_pool = True
         self.fuse_select = True  # scoring + selection + pooling of a sample in one workgroup (bf16 tokens)
         self.score_order = "fold"  # "reference": rank tokens with the reference's own operation order
+        self.overlap_branches = True  # dense (non-pruning) mode: the two attention branches on two streams
         if use_pruning:
             self.v_pruning = PrivacyAwareTokenPruning(
                 prune_ratio=prune_ratio, mixup_alpha=mixup_alpha, adversarial_mix=adversarial_mix,
@@ -331,6 +350,20 @@ class CoAttention(nn.Module):
             attended_q = ops.mean_pool(q_pruned)
         else:
             from .xattn import single_query_attention
-            attended_v = single_query_attention(self.txt_to_vis_attn, q_global, v_seq)  # :257-261
-            attended_q = single_query_attention(self.vis_to_txt_attn, v_global, q_seq)  # :264-268
+            side = _side_stream(v_seq.device) if self.overlap_branches else None
+            if side is not None:
+                # The two branches are independent chains of small launches (a dozen forward, two dozen
+                # backward, each bound by its launch and fill latency at these sizes): on two streams one
+                # chain fills the gaps of the other, forward and backward (autograd runs a node's backward
+                # on the stream of its forward).
+                main = torch.cuda.current_stream(v_seq.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    attended_q = single_query_attention(self.vis_to_txt_attn, v_global, q_seq)  # :264-268
+                attended_v = single_query_attention(self.txt_to_vis_attn, q_global, v_seq)  # :257-261
+                main.wait_stream(side)
+                attended_q.record_stream(main)  # allocated on the side stream, consumed on this one
+            else:
+                attended_v = single_query_attention(self.txt_to_vis_attn, q_global, v_seq)  # :257-261
+                attended_q = single_query_attention(self.vis_to_txt_attn, v_global, q_seq)  # :264-268
         return torch.cat([attended_v, attended_q.to(attended_v.dtype)], dim=1)
