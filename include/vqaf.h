@@ -672,6 +672,31 @@ int vqaf_layernorm_bwd(const void* dy, const void* s, const void* gamma, int par
 int vqaf_gelu_fwd(const void* x, size_t n, int dtype, void* y, vqaf_stream_t stream);
 int vqaf_gelu_bwd(const void* x, const void* dy, size_t n, int dtype, void* dx, vqaf_stream_t stream);
 
+/* Encoder-size Linear on the library's own large-tile bf16 MFMA kernel (model/vision_encoder.py:83-127 and
+ * model/text_encoder.py:14-48 run these layers through torch.nn.Linear inside the pretrained stacks):
+ * y (M,N) bf16 = x (M,K) op(w) (+ bias (N), `bias_dtype`), f32 accumulation.  w is (N,K) with k contiguous
+ * (w_kmajor 0: the forward y = x W^T + b) or (K,N) (w_kmajor 1: the input gradient gx = gy W straight from
+ * the (out,in) weight, no transposed copy); ldx, ldw are row pitches in elements.  epilogue: 0 = bias only;
+ * 1 = also writes aux (M,N) = gelu(y) (y stays the pre-activation the backward needs); 2 = GELU backward,
+ * y = round_bf16(x op(w)) * gelu'(aux) with aux (M,N) the forward's pre-activation and bias NULL.
+ * Needs K % 64 == 0, N % 8 == 0, pitches that are multiples of 8 and 16-byte aligned pointers:
+ * vqaf_linear_nt_supported tells (1/0); other shapes go to vqaf_gemm_bf16. */
+int vqaf_linear_nt_supported(long ldx, long ldw, int w_kmajor, long ldy, int M, int N, int K);
+int vqaf_linear_nt(const void* x, long ldx, const void* w, long ldw, int w_kmajor, const void* bias,
+                   int bias_dtype, int M, int N, int K, void* y, long ldy, int epilogue, void* aux, long ld_aux,
+                   vqaf_stream_t stream);
+/* Weight and bias gradient of such a layer: gw (M,N) `gw_dtype` = gy^T x with gy (K,M) and x (K,N) bf16, K the
+ * token count (the slow index of both: no transposed copies are made); gb (M) `gb_dtype` = column sums of gy,
+ * or NULL.  The token range is split over workgroups when the output alone has too few tiles to fill the
+ * chip; the f32 partial products go to `workspace` (vqaf_wgrad_tn_workspace_bytes(M,N,K) bytes of device
+ * memory, 16-byte aligned) and a second launch adds them in a fixed order, so results are reproducible.
+ * Needs M % 8 == 0, N % 8 == 0, pitches that are multiples of 8, 16-byte aligned pointers. */
+int vqaf_wgrad_tn_supported(long ldg, long ldx, long ld_out, int M, int N, int K);
+size_t vqaf_wgrad_tn_workspace_bytes(int M, int N, int K);
+int vqaf_wgrad_tn(const void* gy, long ldg, const void* x, long ldx, int M, int N, int K, void* gw, long ld_out,
+                  int gw_dtype, void* gb, int gb_dtype, void* workspace, size_t workspace_bytes,
+                  vqaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ python3 - "$out/run_kernel_stats.csv" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-for r in rows[:12]:
-    print(f'calls={r["Calls"]:>5} avg={float(r["AverageNs"])/1e3:8.2f}us min={float(r["MinNs"])/1e3:8.2f} max={float(r["MaxNs"])/1e3:8.2f}  {r["Name"][:80]}')
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+for r in rows[:int(__import__("os").environ.get("PROF_ROWS", "12"))]:
+    print(f'{float(r["TotalDurationNs"])/tot*100:5.1f}% calls={r["Calls"]:>5} avg={float(r["AverageNs"])/1e3:8.2f}us min={float(r["MinNs"])/1e3:8.2f} max={float(r["MaxNs"])/1e3:8.2f}  {r["Name"][:80]}')
 PY

@@ -29,6 +29,10 @@ static inline size_t vqaf_esize(int d) { return d == VQAF_BF16 ? 2 : 4; }
 
 typedef unsigned short bf16_t;  // raw bf16 bits
 
+// Device address of 16 bytes of zeros on the current device (the source of out-of-range operand chunks of
+// the LDS-DMA GEMM kernels); defined in gemm_bf16.hip.  Not part of the C ABI.
+__attribute__((visibility("hidden"))) int vqaf_internal_zero_block(const unsigned int** out);
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));

@@ -760,6 +760,9 @@ void pick_regions(int tiles_m, int tiles_n, int BM, int& reg_m, int& reg_n) {
 
 }  // namespace
 
+// The same block of zeros for the library's other translation units (declared in common.h).
+int vqaf_internal_zero_block(const unsigned int** out) { return zero_block_on_current_device(out); }
+
 extern "C" int vqaf_linear_groupnorm_supported(long ldx, long ldw, int B, int C, int K, int groups) {
   if (groups <= 0 || C % groups != 0 || C % 64 != 0) return 0;
   const int gs = C / groups;

@@ -161,19 +161,46 @@ def gelu(x: torch.Tensor) -> torch.Tensor:
     return _Gelu.apply(x)
 
 
+# token count from which the weight gradient runs on the large-tile kernel (below it the contraction is too
+# short to split into enough slices for 128 x 128 tiles)
+_WGRAD_TN_MIN_TOKENS = 4096
+
+
+def _big_tiles(rows: int, cols: int) -> bool:
+    """Enough 128 x 128 output tiles to fill the chip with the large-tile kernel (vqaf_linear_nt); smaller
+    products run faster on the 128 x 64 / 64 x 64 tiles of vqaf_gemm_bf16."""
+    return ((rows + 127) // 128) * ((cols + 127) // 128) >= 192
+
+
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b for bf16 activations.  Forward and input gradient are plain library GEMMs; the weight
-    gradient dW = dY^T X contracts over the token index, which is the SLOW index of both operands: that is
-    the layout of the clipped-sum GEMM of the DP step, so it runs on the same kernel (vqaf_gemm_bf16, both
-    operands k-major), which also delivers the bias gradient (column sums of dY) from an extra MFMA instead
-    of a second pass over dY."""
+    """y = x W^T + b for bf16 activations, every product on the library's own bf16 MFMA kernels.
+    With enough 128 x 128 output tiles to fill the chip the forward and the input gradient run on the
+    large-tile kernel (vqaf_linear_nt; the input gradient reads W as stored, through transposing LDS reads),
+    and the weight gradient, whose contraction index (the token) is the slow index of both operands, on its
+    k-major twin (vqaf_wgrad_tn), which also delivers the bias gradient from the fragments it multiplies.
+    Smaller products (the text encoder at 30 tokens per sample, the projections of the pooled vector) run on
+    vqaf_gemm_bf16.  Shapes neither covers (pitches that are not multiples of 8) go to torch."""
 
     @staticmethod
     def forward(ctx, x, w, b):
+        from . import ops
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.bdtype = None if b is None else b.dtype
-        return F.linear(x, w, b)
+        out_f, in_f = w.shape
+        x2 = x.reshape(-1, in_f)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T = x2.shape[0]
+        wc = w if w.is_contiguous() else w.contiguous()
+        if _big_tiles(T, out_f) and ops.linear_nt_supported(x2, wc):
+            y = ops.linear_nt(x2, wc, b)
+        elif ops.gemm_bf16_supported(in_f, False, in_f, False, T, out_f, in_f):
+            y = torch.empty(T, out_f, dtype=torch.bfloat16, device=x.device)
+            ops.gemm_bf16(x2, False, wc, False, T, out_f, in_f, y, bias=b)
+        else:
+            return F.linear(x, w, b)
+        return y.view(*x.shape[:-1], out_f)
 
     @staticmethod
     def backward(ctx, gy):
@@ -187,10 +214,22 @@ class _LinearFn(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         T = x2.shape[0]
-        gx = torch.mm(gy2, w).view(x.shape) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            wc = w if w.is_contiguous() else w.contiguous()
+            if _big_tiles(T, in_f) and ops.linear_nt_supported(gy2, wc, True):
+                gx = ops.linear_nt(gy2, wc, None, True)
+            elif ops.gemm_bf16_supported(out_f, False, in_f, True, T, in_f, out_f):
+                gx = torch.empty(T, in_f, dtype=torch.bfloat16, device=gy.device)
+                ops.gemm_bf16(gy2, False, wc, True, T, in_f, out_f, gx)
+            else:
+                gx = torch.mm(gy2, w)
+            gx = gx.view(x.shape)
         gw = gb = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            if ops.gemm_bf16_supported(out_f, True, in_f, True, out_f, in_f, T):
+            if T >= _WGRAD_TN_MIN_TOKENS and ops.wgrad_tn_supported(gy2, x2):
+                gw, gb = ops.wgrad_tn(gy2, x2, w.dtype, ctx.bdtype)
+            elif ops.gemm_bf16_supported(out_f, True, in_f, True, out_f, in_f, T):
                 # An f32 output lets the kernel split the contraction over workgroups when the output has
                 # too few tiles to fill the chip; enough tiles (>= 192 of 128 x 64) go straight to bf16.
                 direct = ((out_f + 127) // 128) * ((in_f + 63) // 64) >= 192
@@ -200,7 +239,7 @@ class _LinearFn(torch.autograd.Function):
                 if not direct:
                     gw = gw.to(w.dtype)
                 gb = None if cs is None else cs.to(ctx.bdtype)
-            else:  # row pitches the kernel does not cover (not multiples of 8): library GEMM
+            else:  # row pitches the kernels do not cover (not multiples of 8): library GEMM
                 gw = torch.mm(gy2.t(), x2)
                 gb = gy2.sum(0).to(ctx.bdtype) if ctx.has_bias else None
         return gx, gw, gb

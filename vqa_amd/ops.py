@@ -854,6 +854,61 @@ def gemm_bf16_wgrad_group(items, K: int, accumulate: bool = False, name: Optiona
     return True
 
 
+def linear_nt_supported(x2: torch.Tensor, w: torch.Tensor, w_kmajor: bool = False) -> bool:
+    """Whether y = x2 op(w) can run on vqaf_linear_nt: x2 (M,K); w (N,K), or (K,N) with w_kmajor; both bf16 with
+    unit inner stride."""
+    for t in (x2, w):
+        if t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1 or t.data_ptr() % 16:
+            return False
+    M, K = x2.shape
+    N = w.shape[1] if w_kmajor else w.shape[0]
+    if (w.shape[0] if w_kmajor else w.shape[1]) != K:
+        return False
+    return bool(load().vqaf_linear_nt_supported(x2.stride(0), w.stride(0), int(w_kmajor), N, M, N, K))
+
+
+@torch.no_grad()
+def linear_nt(x2: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, w_kmajor: bool = False,
+              epilogue: int = 0, aux: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y (M,N) bf16 = x2 (M,K) op(w) (+ bias) on the library's large-tile bf16 MFMA kernel (vqaf_linear_nt).
+    epilogue 1: aux (M,N), allocated by the caller, receives gelu(y); epilogue 2: y = (x2 op(w)) * gelu'(aux)."""
+    M, K = x2.shape
+    N = w.shape[1] if w_kmajor else w.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
+    check(load().vqaf_linear_nt(x2.data_ptr(), x2.stride(0), w.data_ptr(), w.stride(0), int(w_kmajor), ptr(bias),
+                                dtype_code(bias) if bias is not None else 0, M, N, K, y.data_ptr(), N, epilogue,
+                                ptr(aux), aux.stride(0) if aux is not None else 0, stream_ptr(x2.device)),
+          "vqaf_linear_nt")
+    return y
+
+
+def wgrad_tn_supported(gy2: torch.Tensor, x2: torch.Tensor) -> bool:
+    if gy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16 or gy2.stride(1) != 1 or x2.stride(1) != 1:
+        return False
+    if gy2.data_ptr() % 16 or x2.data_ptr() % 16 or gy2.shape[0] != x2.shape[0]:
+        return False
+    K, M = gy2.shape
+    N = x2.shape[1]
+    return bool(load().vqaf_wgrad_tn_supported(gy2.stride(0), x2.stride(0), N, M, N, K))
+
+
+@torch.no_grad()
+def wgrad_tn(gy2: torch.Tensor, x2: torch.Tensor, w_dtype: torch.dtype = torch.bfloat16,
+             bias_dtype: Optional[torch.dtype] = torch.bfloat16):
+    """(gy2^T x2 (M,N) `w_dtype`, column sums of gy2 (M) `bias_dtype` or None) for gy2 (K,M), x2 (K,N) bf16:
+    weight and bias gradient of a Linear whose batch has K tokens (vqaf_wgrad_tn)."""
+    K, M = gy2.shape
+    N = x2.shape[1]
+    lib = load()
+    gw = torch.empty(M, N, dtype=w_dtype, device=gy2.device)
+    gb = torch.empty(M, dtype=bias_dtype, device=gy2.device) if bias_dtype is not None else None
+    ws = torch.empty(lib.vqaf_wgrad_tn_workspace_bytes(M, N, K), dtype=torch.uint8, device=gy2.device)
+    check(lib.vqaf_wgrad_tn(gy2.data_ptr(), gy2.stride(0), x2.data_ptr(), x2.stride(0), M, N, K, gw.data_ptr(), N,
+                            dtype_code(gw), ptr(gb), dtype_code(gb) if gb is not None else 0, ws.data_ptr(),
+                            ws.numel(), stream_ptr(gy2.device)), "vqaf_wgrad_tn")
+    return gw, gb
+
+
 def keep_count(n_tokens: int, prune_ratio: float) -> int:
     """k = max(1, int(N * (1 - prune_ratio))) in Python double arithmetic (utils/fusion.py:41)."""
     return max(1, int(n_tokens * (1 - prune_ratio)))
