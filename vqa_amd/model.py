@@ -64,7 +64,20 @@ class VQAModel(nn.Module):
             v_seq, v_global = self.vision_encoder(images)
             q_seq, q_global = self.text_encoder(input_ids, attention_mask)
         fused = self.fusion_module(v_seq, v_global, q_seq, q_global)
-        return self.classifier(fused)
+        return self._classify(fused)
+
+    def _classify(self, fused):
+        """The classifier head.  Left as built (non-private training, bf16, on the GPU) its Linear layers run
+        on the library's bf16 GEMM kernels like the encoders' do; wrapped for DP-SGD (vqa_amd.dp) or in any
+        other precision it is simply called."""
+        clf = self.classifier
+        if not (type(clf) is nn.Sequential and fused.is_cuda and fused.dtype == torch.bfloat16):
+            return clf(fused)
+        from .encoders import _linear
+        x = fused
+        for layer in clf:
+            x = _linear(x, layer) if type(layer) is nn.Linear else layer(x)
+        return x
 
     @staticmethod
     def _side_stream(device):
