@@ -672,6 +672,19 @@ int vqaf_layernorm_bwd(const void* dy, const void* s, const void* gamma, int par
 int vqaf_gelu_fwd(const void* x, size_t n, int dtype, void* y, vqaf_stream_t stream);
 int vqaf_gelu_bwd(const void* x, const void* dy, size_t n, int dtype, void* dx, vqaf_stream_t stream);
 
+/* Embedding lookups of the text encoder (model/text_encoder.py:14-48: BertModel / RobertaModel add a word, a
+ * position and a token-type row per token).  Forward: out (T,E) `out_dtype` = table0[ids0] + table1[ids1] +
+ * table2[ids2] summed in f32 and rounded once; tables (rows_k, E) `param_dtype`, ids int64 (T); the second and
+ * third table may be NULL.  An index outside its table reads the nearest row.  E % 8 == 0.
+ * Backward: table_grad (rows, E) `param_dtype` = for every row r the sum of g (T,E) `g_dtype` over the tokens
+ * with ids == r, added in token order (reproducible); rows no token names, and row pad_idx (-1: none), are
+ * zero.  T <= 32768. */
+int vqaf_embed_fwd(const long* ids0, const void* table0, long rows0, const long* ids1, const void* table1,
+                   long rows1, const long* ids2, const void* table2, long rows2, int T, int E, int param_dtype,
+                   void* out, int out_dtype, vqaf_stream_t stream);
+int vqaf_embed_bwd(const long* ids, int T, const void* g, int g_dtype, int E, long rows, long pad_idx,
+                   void* table_grad, int param_dtype, vqaf_stream_t stream);
+
 /* Encoder-size Linear on the library's own large-tile bf16 MFMA kernel (model/vision_encoder.py:83-127 and
  * model/text_encoder.py:14-48 run these layers through torch.nn.Linear inside the pretrained stacks):
  * y (M,N) bf16 = x (M,K) op(w) (+ bias (N), `bias_dtype`), f32 accumulation.  w is (N,K) with k contiguous

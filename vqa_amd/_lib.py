@@ -154,6 +154,8 @@ SIGNATURES = {
     "vqaf_layernorm_bwd": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_long, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "vqaf_gelu_fwd": (c_int, [_P, c_size_t, c_int, _P, _P]),
     "vqaf_gelu_bwd": (c_int, [_P, _P, c_size_t, c_int, _P, _P]),
+    "vqaf_embed_fwd": (c_int, [_P, _P, c_long, _P, _P, c_long, _P, _P, c_long, c_int, c_int, c_int, _P, c_int, _P]),
+    "vqaf_embed_bwd": (c_int, [_P, c_int, _P, c_int, c_int, c_long, c_long, _P, c_int, _P]),
     "vqaf_linear_nt_supported": (c_int, [c_long, c_long, c_int, c_long, c_int, c_int, c_int]),
     "vqaf_linear_nt": (c_int, [_P, c_long, _P, c_long, c_int, _P, c_int, c_int, c_int, c_int, _P, c_long, c_int, _P,
                                c_long, _P]),

@@ -485,6 +485,40 @@ class ViTModel(nn.Module):
 # --------------------------------------------------------------------------------------------------
 # BERT
 # --------------------------------------------------------------------------------------------------
+class _EmbeddingSum(torch.autograd.Function):
+    """word[ids] + position[pos_ids] + token_type[type_ids] in one launch (vqaf_embed_fwd); the backward gives
+    each table the sum of the gradient rows of the tokens that name a row, added in token order
+    (vqaf_embed_bwd), the padding row of the word table staying zero as nn.Embedding(padding_idx=...) keeps it."""
+
+    @staticmethod
+    def forward(ctx, word_w, pos_w, type_w, ids, pos_ids, type_ids, out_dtype, pad_idx):
+        E = word_w.shape[1]
+        out = torch.empty(*ids.shape, E, dtype=out_dtype, device=ids.device)
+        check(load().vqaf_embed_fwd(ptr(ids), ptr(word_w), word_w.shape[0], ptr(pos_ids), ptr(pos_w), pos_w.shape[0],
+                                    ptr(type_ids), ptr(type_w), type_w.shape[0], ids.numel(), E, dtype_code(word_w),
+                                    ptr(out), dtype_code(out), stream_ptr(ids.device)), "vqaf_embed_fwd")
+        ctx.save_for_backward(ids, pos_ids, type_ids)
+        ctx.rows = (word_w.shape[0], pos_w.shape[0], type_w.shape[0])
+        ctx.pdtype, ctx.pad = word_w.dtype, pad_idx
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        E = g.shape[-1]
+        grads = []
+        for k, (idx, rows) in enumerate(zip(ctx.saved_tensors, ctx.rows)):
+            if not ctx.needs_input_grad[k]:
+                grads.append(None)
+                continue
+            tg = torch.empty(rows, E, dtype=ctx.pdtype, device=g.device)
+            pad = ctx.pad if (k == 0 and ctx.pad is not None) else -1
+            check(load().vqaf_embed_bwd(ptr(idx), idx.numel(), ptr(g), dtype_code(g), E, rows, pad, ptr(tg),
+                                        dtype_code(tg), stream_ptr(g.device)), "vqaf_embed_bwd")
+            grads.append(tg)
+        return grads[0], grads[1], grads[2], None, None, None, None, None
+
+
 class _BertEmbeddings(nn.Module):
     def __init__(self, cfg: BertConfig):
         super().__init__()
@@ -497,14 +531,25 @@ class _BertEmbeddings(nn.Module):
         self.pad, self.roberta = cfg.pad_token_id, cfg.roberta_positions
 
     def forward(self, input_ids, dtype):
-        L = input_ids.shape[1]
+        B, L = input_ids.shape
+        ww, pw, tw = self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight
+        fused = (input_ids.is_cuda and input_ids.numel() <= 32768 and ww.shape[1] % 8 == 0 and
+                 ww.dtype == pw.dtype == tw.dtype and ww.dtype in (torch.float32, torch.bfloat16) and
+                 dtype in (torch.float32, torch.bfloat16))
         if self.roberta:
             # RobertaEmbeddings: position = pad + (1-based index among the non-padding tokens), pad for padding
             live = (input_ids != self.pad).to(torch.long)
-            pos = self.position_embeddings(torch.cumsum(live, 1) * live + self.pad) + self.token_type_embeddings.weight[0]
+            pos_ids = torch.cumsum(live, 1) * live + self.pad
         else:
-            pos = self.position_embeddings.weight[:L] + self.token_type_embeddings.weight[0]
-        x = (self.word_embeddings(input_ids) + pos).to(dtype)
+            pos_ids = None
+        if fused:
+            ids = input_ids.contiguous()
+            if pos_ids is None:
+                pos_ids = torch.arange(L, device=ids.device).repeat(B, 1)
+            x = _EmbeddingSum.apply(ww, pw, tw, ids, pos_ids.contiguous(), torch.zeros_like(ids), dtype, self.pad)
+        else:
+            pos = (self.position_embeddings(pos_ids) if pos_ids is not None else pw[:L]) + tw[0]
+            x = (self.word_embeddings(input_ids) + pos).to(dtype)
         y, _ = add_layer_norm(x, None, self.LayerNorm.weight, self.LayerNorm.bias, self.eps)
         return F.dropout(y, self.p, self.training)
 
