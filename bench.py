@@ -447,14 +447,20 @@ def full_model_leg(dev):
         print(f"[bench] full-model leg: graph capture unavailable ({type(exc).__name__}: {exc}); eager", file=sys.stderr)
         graph = None
         torch.cuda.synchronize()
-    ms = ms_eager
+    ms, ms_graph = ms_eager, None
     if graph is not None:
         e0.record()
         for _ in range(reps):
             graph.replay()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        ms_graph = e0.elapsed_time(e1) / reps
+        # the headline is the faster of the two launch paths: eager launches overlap the two encoders on two
+        # streams, a replayed graph saves the launch cost but runs its branches with less overlap
+        if ms_graph <= ms_eager:
+            ms = ms_graph
+        else:
+            launch = "eager"
     flops = 0.0
     for T, N in ((B * ((S // 16) ** 2 + 1), (S // 16) ** 2 + 1), (B * L, L)):
         gemm = 2.0 * T * (4 * E * E + 2 * E * FF) * LAYERS
@@ -468,7 +474,8 @@ def full_model_leg(dev):
     return {**out_extra,
             "workload": "ViT-B/16 (224 px) + BERT-base (30 tokens) + CoAttention keep 0.5 + classifier, fwd+bwd, "
                         "batch 64, bf16, non-private, random init",
-            "ms_fwd_bwd": round(ms, 3), "ms_fwd_bwd_eager": round(ms_eager, 3), "launch": launch,
+            "ms_fwd_bwd": round(ms, 3), "ms_fwd_bwd_eager": round(ms_eager, 3),
+            "ms_fwd_bwd_hipgraph": None if ms_graph is None else round(ms_graph, 3), "launch": launch,
             "samples/s": round(B / ms * 1e3, 1), "encoder_TFLOP/s": round(flops / ms / 1e9, 1),
             "frac_of_2500_TFLOPs": round(flops / ms / 1e9 / 2500.0, 4)}
 
