@@ -73,18 +73,18 @@ __global__ __launch_bounds__(256) void embed_bwd_owner_kernel(const long* ids, i
   }
 }
 
-// grid (E / 64, rows): 16 token groups x 16 threads of 4 columns; group j adds tokens j, j+16, ... in order,
-// then the 16 partial sums are added in group order
+// grid (E / 16, rows): 64 token groups x 4 threads of 4 columns; group j adds tokens j, j+64, ... in order,
+// then the 64 partial sums are added in group order
 template <bool GBF16, bool PBF16>
 __global__ __launch_bounds__(256) void embed_bwd_small_kernel(const long* ids, int T, const void* g, int E,
                                                               void* table_grad) {
-  __shared__ float part[16][64];
-  const int tid = threadIdx.x, grp = tid >> 4, cl = (tid & 15) * 4;
-  const int col = blockIdx.x * 64 + cl;
+  __shared__ float part[64][16];
+  const int tid = threadIdx.x, grp = tid >> 2, cl = (tid & 3) * 4;
+  const int col = blockIdx.x * 16 + cl;   // E % 8 == 0: a thread's 4 columns are inside the row or all outside
   const long r = blockIdx.y;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
   if (col < E) {
-    for (int u = grp; u < T; u += 16) {
+    for (int u = grp; u < T; u += 64) {
       if (ids[u] != r) continue;
 #pragma unroll
       for (int e = 0; e < 4; ++e) a[e] += load1<GBF16>(g, (size_t)u * E + col + e);
@@ -93,11 +93,11 @@ __global__ __launch_bounds__(256) void embed_bwd_small_kernel(const long* ids, i
 #pragma unroll
   for (int e = 0; e < 4; ++e) part[grp][cl + e] = a[e];
   __syncthreads();
-  if (tid < 64 && blockIdx.x * 64 + tid < E) {
+  if (tid < 16 && blockIdx.x * 16 + tid < E) {
     float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) s += part[j][tid];
-    store1<PBF16>(table_grad, (size_t)r * E + blockIdx.x * 64 + tid, s);
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) s += part[j][tid];
+    store1<PBF16>(table_grad, (size_t)r * E + blockIdx.x * 16 + tid, s);
   }
 }
 
@@ -138,7 +138,7 @@ extern "C" int vqaf_embed_bwd(const long* ids, int T, const void* g, int g_dtype
   if (hipMemsetAsync(table_grad, 0, (size_t)rows * E * vqaf_esize(param_dtype), st) != hipSuccess) return VQAF_E_LAUNCH;
   const bool gb = g_dtype == VQAF_BF16, pb = param_dtype == VQAF_BF16;
   if (rows <= 8) {
-    const dim3 grid((unsigned)((E + 63) / 64), (unsigned)rows);
+    const dim3 grid((unsigned)((E + 15) / 16), (unsigned)rows);
 #define EM_SM(G, P) hipLaunchKernelGGL((embed_bwd_small_kernel<G, P>), grid, dim3(256), 0, st, ids, T, g, E, table_grad)
     if (gb && pb) EM_SM(true, true);
     else if (gb) EM_SM(true, false);
