@@ -32,6 +32,12 @@ typedef unsigned short bf16_t;  // raw bf16 bits
 // Device address of 16 bytes of zeros on the current device (the source of out-of-range operand chunks of
 // the LDS-DMA GEMM kernels); defined in gemm_bf16.hip.  Not part of the C ABI.
 __attribute__((visibility("hidden"))) int vqaf_internal_zero_block(const unsigned int** out);
+// The 256 x 256-tile weight-gradient kernel (wgrad256.hip) behind vqaf_wgrad_tn: how it cuts the token range, and
+// the launch of its partial products into slabs (splits x M*N f32; cs_slabs: splits x M column sums, or NULL).
+__attribute__((visibility("hidden"))) void vqaf_internal_wgrad256_plan(int M, int N, int K, int* k_per_split, int* splits);
+__attribute__((visibility("hidden"))) int vqaf_internal_wgrad256_launch(const void* gy, long ldg, const void* x, long ldx,
+                                                                        int M, int N, int K, float* slabs,
+                                                                        float* cs_slabs, hipStream_t st);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

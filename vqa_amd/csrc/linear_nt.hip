@@ -11,6 +11,7 @@
 // k-step of 64 is resident per workgroup; three workgroups per CU overlap each other's fetches.
 // Output tiles go through LDS so that every store instruction writes whole 128-byte row pieces, and the
 // epilogue works on 8 consecutive channels per lane.
+
 #include "common.h"
 
 namespace {
@@ -78,15 +79,17 @@ __global__ __launch_bounds__(LN_THREADS, 3) void linear_nt_kernel(const LinArgs 
   //      (k-major W: chunk -> (k row q / 16, position q % 16) holding source chunk position ^ ((k & 3) << 2))
   const bf16_t* xs[4];
   const bf16_t* ws[4];
+  bool w_ok[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int qq = j * LN_THREADS + tid, row = qq >> 3, c = (qq & 7) ^ ln_swz(row);
     xs[j] = g.X + (long)min(m0 + row, g.M - 1) * g.ldx + c * 8;   // rows past the edge repeat the last row;
     if constexpr (W_KMAJOR) {
       const int k = qq >> 4, cw = (qq & 15) ^ ((k & 3) << 2);
-      // columns past the edge come from the block of zeros (the pointer never advances then)
-      ws[j] = n0 + cw * 8 < g.N ? g.W + (long)k * g.ldw + n0 + cw * 8 : nullptr;
+      w_ok[j] = n0 + cw * 8 < g.N;   // columns past the edge come from the block of zeros
+      ws[j] = g.W + (long)k * g.ldw + (w_ok[j] ? n0 + cw * 8 : 0);
     } else {
+      w_ok[j] = true;
       ws[j] = g.W + (long)min(n0 + row, g.N - 1) * g.ldw + c * 8;   // their outputs are never stored
     }
   }
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(LN_THREADS, 3) void linear_nt_kernel(const LinArgs 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const void* src = ws[j] + (long)t * w_step;
-      if constexpr (W_KMAJOR) src = ws[j] != nullptr ? src : reinterpret_cast<const void*>(g.zeros);
+      if constexpr (W_KMAJOR) src = w_ok[j] ? src : reinterpret_cast<const void*>(g.zeros);
       ln_glds16(src, dma_w + j * 4096);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -158,22 +161,51 @@ __global__ __launch_bounds__(LN_THREADS, 3) void linear_nt_kernel(const LinArgs 
   // ---- epilogue.  acc[i][j][e]: token m = wm*64 + i*32 + (lane & 31),
   //      channel n = wn*64 + j*32 + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
   unsigned char* const img = lds + wave * (64 * LN_CP);   // this wave's 64 tokens x 64 channels, bf16
+  // Everything the epilogue reads from memory is requested here in one batch (one round trip instead of
+  // one per use): the lane's 8 runs of 4 bias values, and for the GELU backward its 8 pieces of the
+  // pre-activation.
+  float bv[8][4];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[q][e] = 0.f;
+  if (EPI != LN_EPI_GELU_BWD && g.bias != nullptr) {
+    if (g.bias_bf16) {
+      u32x2 raw[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int n = min(n0 + wn * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * khalf, g.N - 4);
+        raw[q] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(g.bias) + n);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        bv[q][0] = bf16_lo(raw[q].x); bv[q][1] = bf16_hi(raw[q].x);
+        bv[q][2] = bf16_lo(raw[q].y); bv[q][3] = bf16_hi(raw[q].y);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int n = min(n0 + wn * 64 + (q >> 2) * 32 + 8 * (q & 3) + 4 * khalf, g.N - 4);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.bias) + n);
+        bv[q][0] = bb.x; bv[q][1] = bb.y; bv[q][2] = bb.z; bv[q][3] = bb.w;
+      }
+    }
+  }
+  u32x4 hv[8];
+  if constexpr (EPI == LN_EPI_GELU_BWD) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int m = min(m0 + wm * 64 + it * 8 + (lane >> 3), g.M - 1);
+      const int n = min(n0 + wn * 64 + 8 * (lane & 7), g.N - 8);
+      hv[it] = *reinterpret_cast<const u32x4*>(g.H + (long)m * g.ld2 + n);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       const int nl = j * 32 + 8 * rq + 4 * khalf;   // channel within the wave's 64
-      float b[4] = {0.f, 0.f, 0.f, 0.f};
-      if (EPI != LN_EPI_GELU_BWD && g.bias != nullptr) {
-        const int n = min(n0 + wn * 64 + nl, g.N - 4);
-        if (g.bias_bf16) {
-          const u32x2 bb = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(g.bias) + n);
-          b[0] = bf16_lo(bb.x); b[1] = bf16_hi(bb.x); b[2] = bf16_lo(bb.y); b[3] = bf16_hi(bb.y);
-        } else {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.bias) + n);
-          b[0] = bb.x; b[1] = bb.y; b[2] = bb.z; b[3] = bb.w;
-        }
-      }
+      const float* b = bv[j * 4 + rq];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ml = i * 32 + (lane & 31);
@@ -201,7 +233,7 @@ __global__ __launch_bounds__(LN_THREADS, 3) void linear_nt_kernel(const LinArgs 
         o.w = pack_bf16x2(ln_gelu(bf16_lo(v.w)), ln_gelu(bf16_hi(v.w)));
         *reinterpret_cast<u32x4*>(g.Y2 + (long)m * g.ld2 + n) = o;
       } else {
-        const u32x4 h = *reinterpret_cast<const u32x4*>(g.H + (long)m * g.ld2 + n);
+        const u32x4 h = hv[it];
         u32x4 o;
         o.x = pack_bf16x2(bf16_lo(v.x) * ln_gelu_grad(bf16_lo(h.x)), bf16_hi(v.x) * ln_gelu_grad(bf16_hi(h.x)));
         o.y = pack_bf16x2(bf16_lo(v.y) * ln_gelu_grad(bf16_lo(h.y)), bf16_hi(v.y) * ln_gelu_grad(bf16_hi(h.y)));
@@ -469,10 +501,18 @@ extern "C" int vqaf_wgrad_tn_supported(long ldg, long ldx, long ld_out, int M, i
           ldg % 8 == 0 && ldx % 8 == 0 && ld_out % 8 == 0 && (size_t)M * N / 8 / 256 < 0x7fffff00UL) ? 1 : 0;
 }
 
+// Large outputs with a long token range run on the 256 x 256-tile kernel (wgrad256.hip).
+// (measured at 12608 tokens: 3072 x 768 80 against 87 us with the reduction, 2304 x 768 68 against 74;
+// 768 x 768, nine tiles cut into 28 slices, is faster on the 128 x 128 tiles)
+static bool wgrad_use256(int M, int N, int K) {
+  return M >= 256 && N >= 256 && (long)M * N >= (1L << 20) && K >= 4096;
+}
+
 extern "C" size_t vqaf_wgrad_tn_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   int kps, splits;
-  wgrad_plan(M, N, K, &kps, &splits);
+  if (wgrad_use256(M, N, K)) vqaf_internal_wgrad256_plan(M, N, K, &kps, &splits);
+  else wgrad_plan(M, N, K, &kps, &splits);
   return (size_t)splits * ((size_t)M * N + M) * sizeof(float);
 }
 
@@ -487,20 +527,27 @@ extern "C" int vqaf_wgrad_tn(const void* gy, long ldg, const void* x, long ldx, 
                VQAF_E_ALIGN);
   VQAF_REQUIRE(workspace_bytes >= vqaf_wgrad_tn_workspace_bytes(M, N, K), VQAF_E_SHAPE);
   WgradArgs g;
-  VQAF_REQUIRE(vqaf_internal_zero_block(&g.zeros) == VQAF_OK, VQAF_E_LAUNCH);
-  wgrad_plan(M, N, K, &g.k_per_split, &g.splits);
-  g.G = reinterpret_cast<const bf16_t*>(gy);
-  g.X = reinterpret_cast<const bf16_t*>(x);
-  g.slabs = reinterpret_cast<float*>(workspace);
-  g.cs_slabs = gb != nullptr ? g.slabs + (size_t)g.splits * M * N : nullptr;
-  g.ldg = ldg; g.ldx = ldx;
-  g.M = M; g.N = N; g.K = K;
-  g.tiles_m = (M + LN_BM - 1) / LN_BM;
-  g.tiles_n = (N + LN_BN - 1) / LN_BN;
-  const long nt = (long)g.tiles_m * g.tiles_n;
-  VQAF_REQUIRE(nt * g.splits < 0x7fffffffL, VQAF_E_SHAPE);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)(nt * g.splits)), dim3(LN_THREADS), 0, st, g);
+  g.slabs = reinterpret_cast<float*>(workspace);
+  if (wgrad_use256(M, N, K)) {
+    vqaf_internal_wgrad256_plan(M, N, K, &g.k_per_split, &g.splits);
+    g.cs_slabs = gb != nullptr ? g.slabs + (size_t)g.splits * M * N : nullptr;
+    const int rc = vqaf_internal_wgrad256_launch(gy, ldg, x, ldx, M, N, K, g.slabs, g.cs_slabs, st);
+    if (rc != VQAF_OK) return rc;
+  } else {
+    VQAF_REQUIRE(vqaf_internal_zero_block(&g.zeros) == VQAF_OK, VQAF_E_LAUNCH);
+    wgrad_plan(M, N, K, &g.k_per_split, &g.splits);
+    g.G = reinterpret_cast<const bf16_t*>(gy);
+    g.X = reinterpret_cast<const bf16_t*>(x);
+    g.cs_slabs = gb != nullptr ? g.slabs + (size_t)g.splits * M * N : nullptr;
+    g.ldg = ldg; g.ldx = ldx;
+    g.M = M; g.N = N; g.K = K;
+    g.tiles_m = (M + LN_BM - 1) / LN_BM;
+    g.tiles_n = (N + LN_BN - 1) / LN_BN;
+    const long nt = (long)g.tiles_m * g.tiles_n;
+    VQAF_REQUIRE(nt * g.splits < 0x7fffffffL, VQAF_E_SHAPE);
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)(nt * g.splits)), dim3(LN_THREADS), 0, st, g);
+  }
   const size_t work = (size_t)M * N / 8 + (gb != nullptr ? (size_t)M : 0);
   const dim3 rgrid((unsigned)((work + 255) / 256));
   const bool ob = gw_dtype == VQAF_BF16, bb = gb_dtype == VQAF_BF16;
