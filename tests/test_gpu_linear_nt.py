@@ -129,3 +129,26 @@ def test_weight_and_bias_gradient(K, M, N, out):
     assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
     gw3, none = ops.wgrad_tn(gy, x, dt, None)
     assert none is None and torch.equal(gw3, gw)
+
+
+@pytest.mark.parametrize("T,in_f,out_f", [(6304, 768, 3072), (6304, 3072, 768), (4200, 768, 768)])
+def test_encoder_linear_function_on_the_large_tile_kernels(T, in_f, out_f):
+    """encoders._LinearFn at token counts where all three products take the large-tile kernels (forward and
+    input gradient on vqaf_linear_nt, weight + bias gradient on vqaf_wgrad_tn) against torch autograd in f64."""
+    from vqa_amd import encoders
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(T + in_f)
+    x = torch.randn(2, T // 2, in_f, generator=g).bfloat16().to(dev).requires_grad_()
+    w = (torch.randn(out_f, in_f, generator=g) * 0.03).bfloat16().to(dev).requires_grad_()
+    b = torch.randn(out_f, generator=g).bfloat16().to(dev).requires_grad_()
+    assert encoders._big_tiles(T, out_f) and encoders._big_tiles(T, in_f) and T >= encoders._WGRAD_TN_MIN_TOKENS
+    y = encoders._LinearFn.apply(x, w, b)
+    cot = torch.randn(2, T // 2, out_f, generator=g).bfloat16().to(dev)
+    y.backward(cot)
+    x64, w64, b64 = (t.detach().double().requires_grad_() for t in (x, w, b))
+    y64 = torch.nn.functional.linear(x64, w64, b64)
+    y64.backward(cot.double())
+    assert y.shape == y64.shape
+    for got, want in ((y, y64), (x.grad, x64.grad), (w.grad, w64.grad), (b.grad, b64.grad)):
+        assert got.dtype == torch.bfloat16
+        _close(got, want.detach())
