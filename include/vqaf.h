@@ -83,6 +83,13 @@ typedef struct vqaf_fold_desc {
 } vqaf_fold_desc;
 int vqaf_fold_query_multi(const vqaf_fold_desc* descs_host, int n, int B, int D, int H, int dtype,
                           int w_dtype, vqaf_stream_t stream);
+/* The same call that also adds `delta` to count_state[1] ({seed, counter} uint64 pair in device memory) on
+ * the side: the generator positions the launch BEHIND it is about to consume (vqaf_fused_prune_pool_multi
+ * with rng_advance = -delta draws from the position the counter had before), so that no launch of its own
+ * is spent on the counter.  utils/fusion.py:48-65 draws fresh positions in every forward; this is that
+ * bookkeeping for a replayed HIP graph.  The folds themselves never read count_state. */
+int vqaf_fold_query_multi_advance(const vqaf_fold_desc* descs_host, int n, int B, int D, int H, int dtype,
+                                  int w_dtype, uint64_t* count_state, uint64_t delta, vqaf_stream_t stream);
 
 /* s (B,N,H) f32  <-  seq (B,N,D) `dtype`, u (B,H,D) f32.  Raw per-head scaled scores.
  * With bf16 tokens, H <= 8 and D in {64,128,256,512,768,1024} the products run on bf16 MFMA:
@@ -314,7 +321,11 @@ typedef struct vqaf_fused_mod {
 /* rng_advance > 0: `sel_rng_state` is a FOUR-word state {seed, counter, ticket, reserved} (ticket zero)
  * and the last workgroup of the launch adds rng_advance to its counter, which replaces the
  * vqaf_rng_advance launch(es) that would follow; every noise_rng_state must then be the same state.
- * rng_advance == 0: two words suffice and the caller advances. */
+ * rng_advance == 0: two words suffice and the caller advances.
+ * rng_advance < 0: the counter of `sel_rng_state` (two words) was ALREADY advanced by -rng_advance before
+ * this launch (vqaf_fold_query_multi_advance); selection and any noise stream that is the same state draw from
+ * the positions counter + rng_advance ..., i.e. the values of the rng_advance == 0 call followed by the
+ * caller's advance. */
 int vqaf_fused_prune_pool_multi(const vqaf_fused_mod* mods_host, int n_mod, int B, int D, int H, int dtype,
                                 uint64_t* sel_rng_state, int rng_advance, void* out, int ld_out,
                                 int out_dtype, vqaf_stream_t stream);
@@ -515,6 +526,17 @@ int vqaf_ghost_clip_zero(int n_layers, const void* const* a_host, const void* co
                          float* norms, float* sq, float* const* zero_ptrs_host,
                          const size_t* zero_counts_host, int n_zero, vqaf_stream_t stream);
 
+/* vqaf_ghost_clip_zero that also adds 1 to count_state[1] ({unused, count} uint64 pair in device memory, or
+ * NULL): the update count of the step that follows (vqaf_dp_adamw with step_advance = -1), so that no launch
+ * of its own is spent on it.  Nothing this launch reads may alias count_state.  The DP optimizer's per-step
+ * bookkeeping around train.py:130-141 / utils/src.py:104. */
+int vqaf_ghost_clip_zero_bump(int n_layers, const void* const* a_host, const void* const* g_host,
+                              const int* in_dim_host, const int* out_dim_host, const int* kind_host, int B,
+                              int dtype, float max_norm, float scale, int scale_g_inplace, float* coef,
+                              float* norms, float* sq, float* const* zero_ptrs_host,
+                              const size_t* zero_counts_host, int n_zero, uint64_t* count_state,
+                              vqaf_stream_t stream);
+
 /* Clipped gradient sum of a Linear:  SW (Out,In) f32 = sum_b coef[b] g_b a_b^T,
  * Sb (Out) f32 = sum_b coef[b] g_b (Sb may be NULL).  bf16 inputs use bf16 MFMA, f32
  * inputs the exact f32 MFMA.  accumulate != 0 adds into SW / Sb (micro-batching).
@@ -551,7 +573,10 @@ int vqaf_noise_scale(const float* S, const float* noise, const uint64_t* rng_sta
  * `step` = uint64 words in device memory {unused, updates applied so far}: with step_advance == 0
  * two words, advanced by the caller (vqaf_rng_advance) after the call; with step_advance > 0 FOUR
  * words {unused, updates, ticket, reserved} (ticket zero) and the last workgroup adds step_advance
- * to the count itself.  `step` may double as rng_state.  shadow_bf16 (n bf16, may be NULL) receives the updated
+ * to the count itself; with step_advance == -1 the count was ALREADY advanced by one for this update before
+ * the launch (vqaf_ghost_clip_zero_bump): t = step[1], and a rng_state that is the same pair draws from
+ * counter step[1] - 1, i.e. exactly what the launch with step_advance == 0 followed by the caller's advance
+ * computes.  `step` may double as rng_state.  shadow_bf16 (n bf16, may be NULL) receives the updated
  * parameters rounded to bf16; grad_out (n f32, may be NULL, may alias S) receives g.
  * This is the step train.py:130-141 configures: AdamW on the classifier wrapped by the DP
  * optimizer (utils/src.py:104). */

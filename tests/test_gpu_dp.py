@@ -666,6 +666,33 @@ def test_in_kernel_counter_bumps_and_zero_multi(dev):
                                 1e-3, 0.9, 0.999, 1e-8, 0.01, ptr(sb), 0, st), "adamw")
         check(lib.vqaf_rng_advance(ptr(sb), 1, st), "adv")
     assert torch.equal(P2, P3) and torch.equal(M2, M3) and torch.equal(V2, V3) and torch.equal(sa, sb)
+    # ... and with the count advanced BEFORE the update (step_advance = -1: what the clipping launch of a
+    # step does on the side): the same draws and bias corrections again
+    P4, M4, V4 = torch.ones(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    sc = ops.PhiloxState(dev, seed=9).state
+    for _ in range(3):
+        check(lib.vqaf_rng_advance(ptr(sc), 1, st), "adv")
+        check(lib.vqaf_dp_adamw(ptr(S), None, ptr(sc), 1.0, 1.0 / 64, ptr(P4), ptr(M4), ptr(V4), None, None, n,
+                                1e-3, 0.9, 0.999, 1e-8, 0.01, ptr(sc), -1, st), "adamw")
+    assert torch.equal(P4, P3) and torch.equal(M4, M3) and torch.equal(V4, V3) and torch.equal(sc, sb)
+    # the clipping launch advancing a count on the side: same coefficients, count + 1, nothing else touched
+    Bq = 37
+    a = torch.randn(Bq, 64, device=dev).bfloat16()
+    g = (torch.randn(Bq, 48, device=dev) * 0.1).bfloat16()
+    outs = []
+    for count in (None, ops.PhiloxState(dev, seed=3).state):
+        gg = g.clone()
+        coef, norms = torch.empty(Bq, device=dev), torch.empty(Bq, device=dev)
+        before = count.clone() if count is not None else None
+        pa, pg = (ctypes.c_void_p * 1)(ptr(a)), (ctypes.c_void_p * 1)(ptr(gg))
+        din, dout, kind = (ctypes.c_int * 1)(64), (ctypes.c_int * 1)(48), (ctypes.c_int * 1)(1)
+        check(lib.vqaf_ghost_clip_zero_bump(1, pa, pg, din, dout, kind, Bq, 1, 1.0, 1.0, 1, ptr(coef), ptr(norms),
+                                            None, None, None, 0, ptr(count), st), "ghost_clip_zero_bump")
+        outs.append((coef.clone(), norms.clone(), gg))
+        if count is not None:
+            assert count[1].item() == before[1].item() + 1 and count[0].item() == before[0].item()
+            assert count[2:].tolist() == before[2:].tolist()
+    assert all(torch.equal(x, y) for x, y in zip(*outs))
     # zero_multi
     buf = torch.ones(10000, device=dev)
     ranges = [buf[3:10], buf[100:1124], buf[5000:5001], buf[6001:9000]]

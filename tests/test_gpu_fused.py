@@ -72,6 +72,29 @@ def test_one_launch_branch_equals_separate_launches(dev, B, Nv, Nq, noise):
     assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
 
 
+@pytest.mark.parametrize("noise", [False, True])
+def test_counter_advanced_by_the_fold_launch_equals_the_separate_counter_launch(dev, noise):
+    """The query-fold launch advancing the generator state on the side (the default) and the separate
+    counter launches give the same draws, the same results bit for bit and the same final state."""
+    from vqa_amd import ops
+    B, Nv, Nq = 9, 197, 30
+    v, vg = gi.tokens(1, B, Nv)
+    q, qg = gi.tokens(2, B, Nq)
+    v, vg, q, qg = (t.to(dev).bfloat16() for t in (v, vg, q, qg))
+    cot = gi.normal(11, B, 1024).to(dev)
+    m = _module(dev, noise_injection=noise, noise_scale=0.05).bfloat16()
+    saved = ops.ADVANCE_RNG_IN_FOLD
+    try:
+        ops.ADVANCE_RNG_IN_FOLD = True
+        a = _run(m, True, v, vg, q, qg, cot, 77)
+        ops.ADVANCE_RNG_IN_FOLD = False
+        b = _run(m, True, v, vg, q, qg, cot, 77)
+    finally:
+        ops.ADVANCE_RNG_IN_FOLD = saved
+    assert all(torch.equal(x, y) for x, y in zip(a[:5], b[:5])) and a[5] == b[5]
+    assert a[5] == (2 if noise else 1)
+
+
 def test_one_launch_branch_vs_oracle(dev):
     """Against the reference's op sequence on the same bf16-rounded tokens (f32 arithmetic): indices
     equal, fused features and input gradients within the bf16 bar."""

@@ -67,6 +67,7 @@ SIGNATURES = {
     "vqaf_status_string": (c_char_p, [c_int]),
     "vqaf_fold_query": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_fold_query_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vqaf_fold_query_multi_advance": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_uint64, _P]),
     "vqaf_head_scores": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "vqaf_head_scores_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),
     "vqaf_attn_weights": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
@@ -131,6 +132,8 @@ SIGNATURES = {
                                 _P]),
     "vqaf_ghost_clip_zero": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int, _P, _P, _P,
                                      _P, _P, c_int, _P]),
+    "vqaf_ghost_clip_zero_bump": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int, _P, _P,
+                                          _P, _P, _P, c_int, _P, _P]),
     "vqaf_clipped_sum_linear": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_clipped_sum_affine": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "vqaf_clipped_sum_affine_multi": (c_int, [c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, _P]),

@@ -80,6 +80,7 @@ struct GhostZero {
   float* p[GC_MAX_ZERO];
   unsigned int n[GC_MAX_ZERO];  // elements
   int count;
+  unsigned long long* bump;  // {unused, count} pair whose count one thread of the launch advances by 1, or NULL
 };
 __device__ __forceinline__ void ghost_zero_ranges(const GhostZero& Z) {
   const unsigned int stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,6 +88,8 @@ __device__ __forceinline__ void ghost_zero_ranges(const GhostZero& Z) {
   for (int r = 0; r < GC_MAX_ZERO; ++r)
     if (r < Z.count)
       for (unsigned int i = first; i < Z.n[r]; i += stride) Z.p[r][i] = 0.f;
+  // nothing in this launch reads the count, and launches on one stream do not overlap: a plain store
+  if (Z.bump != nullptr && first == 0) Z.bump[1] = Z.bump[1] + 1ull;
 }
 struct GhostLayers {
   const void* a[GC_MAX_LAYERS];
@@ -752,11 +755,13 @@ dp_adamw_kernel(const float* __restrict__ S, const float* __restrict__ noise,
                 float beta2, float eps, float weight_decay, uint64_t* step, int advance) {
   unsigned long long seed = 0, counter = 0;
   const bool draw = (noise == nullptr) && (noise_std != 0.f);
+  // advance < 0: the count was already advanced by one for this step before the launch
+  const unsigned long long pre = advance < 0 ? 1ull : 0ull;
   if (draw) {
     seed = rng_state[0];
-    counter = rng_state[1];
+    counter = rng_state[1] - (rng_state == step ? pre : 0ull);
   }
-  const VqafAdamConsts ac = vqaf_adam_consts(step[1], noise_std, scale, lr, beta1, beta2, eps, weight_decay);
+  const VqafAdamConsts ac = vqaf_adam_consts(step[1] - pre, noise_std, scale, lr, beta1, beta2, eps, weight_decay);
   const size_t ncall = (n + 3) >> 2;
   for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncall;
        c += (size_t)gridDim.x * blockDim.x) {
@@ -812,7 +817,7 @@ dp_adamw_kernel(const float* __restrict__ S, const float* __restrict__ noise,
     }
   }
   // `step` (which may also be the noise state) was read before the loop by every thread
-  if (advance != 0) vqaf_rng_bump_by_last_workgroup(step, (unsigned long long)advance, gridDim.x);
+  if (advance > 0) vqaf_rng_bump_by_last_workgroup(step, (unsigned long long)advance, gridDim.x);
 }
 
 // The same update over up to eight RANGES of the flat buckets in one launch (blockIdx.y picks the range).
@@ -1239,6 +1244,28 @@ extern "C" int vqaf_ghost_clip_zero(int n_layers, const void* const* a_host, con
                            scale_g_inplace, coef, norms, sq, Z, stream);
 }
 
+extern "C" int vqaf_ghost_clip_zero_bump(int n_layers, const void* const* a_host, const void* const* g_host,
+                                         const int* in_dim_host, const int* out_dim_host, const int* kind_host,
+                                         int B, int dtype, float max_norm, float scale, int scale_g_inplace,
+                                         float* coef, float* norms, float* sq, float* const* zero_ptrs_host,
+                                         const size_t* zero_counts_host, int n_zero, uint64_t* count_state,
+                                         vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(n_zero >= 0 && n_zero <= GC_MAX_ZERO, VQAF_E_SHAPE);
+  VQAF_REQUIRE(n_zero == 0 || (zero_ptrs_host && zero_counts_host), VQAF_E_NULL);
+  GhostZero Z = {};
+  for (int i = 0; i < n_zero; ++i) {
+    VQAF_REQUIRE(zero_ptrs_host[i] != nullptr, VQAF_E_NULL);
+    VQAF_REQUIRE(zero_counts_host[i] < (1ull << 32), VQAF_E_SHAPE);
+    Z.p[i] = zero_ptrs_host[i];
+    Z.n[i] = (unsigned int)zero_counts_host[i];
+  }
+  Z.count = n_zero;
+  Z.bump = reinterpret_cast<unsigned long long*>(count_state);
+  return ghost_clip_launch(n_layers, a_host, g_host, in_dim_host, out_dim_host, kind_host, B, dtype, max_norm, scale,
+                           scale_g_inplace, coef, norms, sq, Z, stream);
+}
+
 extern "C" int vqaf_clipped_sum_linear(const void* a, const void* g, const float* coef, int B,
                                        int In, int Out, int dtype, int accumulate, float* SW,
                                        float* Sb, vqaf_stream_t stream) {
@@ -1420,7 +1447,7 @@ extern "C" int vqaf_dp_adamw(const float* S, const float* noise, const uint64_t*
                              uint64_t* step, int step_advance, vqaf_stream_t stream) {
   VQAF_ENTRY();
   VQAF_REQUIRE(S && param && exp_avg && exp_avg_sq && step, VQAF_E_NULL);
-  VQAF_REQUIRE(n > 0 && step_advance >= 0, VQAF_E_SHAPE);
+  VQAF_REQUIRE(n > 0 && step_advance >= -1, VQAF_E_SHAPE);
   VQAF_REQUIRE(noise != nullptr || noise_std == 0.f || rng_state != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(vqaf_aligned16(S) && vqaf_aligned16(param) && vqaf_aligned16(exp_avg) &&
                    vqaf_aligned16(exp_avg_sq) && (noise == nullptr || vqaf_aligned16(noise)) &&

@@ -109,7 +109,9 @@ fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, uint64_t* sel_rng,
   unsigned long long seed = 0, counter = 0;
   if (M.adv_mode == 2) {
     seed = sel_rng[0] + M.salt;
-    counter = sel_rng[1];
+    // rng_advance < 0: the counter was advanced by -rng_advance BEFORE this launch (by the launch in front
+    // of it); the draws use the position it had then
+    counter = sel_rng[1] + (unsigned long long)(long long)(rng_advance < 0 ? rng_advance : 0);
   }
 
   // ------------------------------- pass 1: head scores -----------------------------------
@@ -250,7 +252,8 @@ fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, uint64_t* sel_rng,
     }
   } else if (M.noise_kind != VQAF_NOISE_NONE) {
     const unsigned long long nseed = M.noise_rng[0];
-    const unsigned long long ncounter = M.noise_rng[1] + (unsigned long long)M.noise_ctr_off;
+    const unsigned long long ncounter = M.noise_rng[1] + (unsigned long long)M.noise_ctr_off +
+        (unsigned long long)(long long)((rng_advance < 0 && M.noise_rng == sel_rng) ? rng_advance : 0);
     for (int j = g; j < K; j += ROWS)
       vqaf_token_noise8(acck, nullptr, M.noise_kind, M.noise_scale, nseed, ncounter, ((size_t)b * K + j) * D + d0);
   }
@@ -279,7 +282,7 @@ fused_prune_pool_kernel(FusedMods mods, int n_mod, int H, uint64_t* sel_rng,
     else reinterpret_cast<float*>(out)[o] = r;
   }
   // every draw of this workgroup (selection above, noise in pass 2) has read the state by now
-  if (rng_advance != 0)
+  if (rng_advance > 0)
     vqaf_rng_bump_by_last_workgroup(sel_rng, (unsigned long long)rng_advance, gridDim.x * gridDim.y);
 }
 
@@ -431,7 +434,9 @@ fused_onepass_kernel(FusedMods mods, int n_mod, int H, uint64_t* sel_rng, void* 
     unsigned long long seed = 0, counter = 0;
     if (M.adv_mode == 2) {
       seed = sel_rng[0] + M.salt;
-      counter = sel_rng[1];
+      // rng_advance < 0: the counter was advanced by -rng_advance BEFORE this launch (by the launch in front
+      // of it); the draws use the position it had then
+      counter = sel_rng[1] + (unsigned long long)(long long)(rng_advance < 0 ? rng_advance : 0);
     }
     // folded queries first: their data is wanted first and loads return in issue order
     f32x4 uv[4];
@@ -644,7 +649,8 @@ fused_onepass_kernel(FusedMods mods, int n_mod, int H, uint64_t* sel_rng, void* 
         }
       } else {
         const unsigned long long nseed = M.noise_rng[0];
-        const unsigned long long ncounter = M.noise_rng[1] + (unsigned long long)M.noise_ctr_off;
+        const unsigned long long ncounter = M.noise_rng[1] + (unsigned long long)M.noise_ctr_off +
+        (unsigned long long)(long long)((rng_advance < 0 && M.noise_rng == sel_rng) ? rng_advance : 0);
         for (int j = g; j < K; j += OP_WAVES)
           vqaf_token_noise8(acck, nullptr, M.noise_kind, M.noise_scale, nseed, ncounter, ((size_t)b * K + j) * D + d0);
       }
@@ -683,7 +689,7 @@ fused_onepass_kernel(FusedMods mods, int n_mod, int H, uint64_t* sel_rng, void* 
       for (int i = 0; i < 6; ++i) reinterpret_cast<unsigned long long*>(M.w_out)[(size_t)b * 24 + 10 + i] = sel_stamps_lds[i];
 #endif
   }
-  if (rng_advance != 0)
+  if (rng_advance > 0)
     vqaf_rng_bump_by_last_workgroup(sel_rng, (unsigned long long)rng_advance, gridDim.x * gridDim.y);
 }
 
@@ -694,7 +700,7 @@ static int fused_prune_pool_launch(const vqaf_fused_mod* mods_host, int n_mod, i
                                    int ld_out, int out_dtype, vqaf_stream_t stream, bool allow_one_pass) {
   VQAF_ENTRY();
   VQAF_REQUIRE(mods_host != nullptr && out != nullptr, VQAF_E_NULL);
-  VQAF_REQUIRE(rng_advance >= 0 && (rng_advance == 0 || sel_rng_state != nullptr), VQAF_E_NULL);
+  VQAF_REQUIRE(rng_advance == 0 || sel_rng_state != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(dtype == VQAF_BF16 && vqaf_dtype_ok(out_dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(n_mod > 0 && n_mod <= FU_MAX_MODS && B > 0 && H > 0 && H <= 8, VQAF_E_SHAPE);
   VQAF_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512 || D == 1024, VQAF_E_SHAPE);

@@ -331,7 +331,10 @@ __device__ __forceinline__ void fq_split_store(float x, unsigned char* plane0_el
 }
 
 __global__ void __launch_bounds__(FQ_THREADS)
-fold_query_bf16_kernel(FoldSets sets, int B, int H) {
+fold_query_bf16_kernel(FoldSets sets, int B, int H, unsigned long long* count_state, unsigned long long delta) {
+  // a {seed, counter} pair advanced on the side (nothing in this launch reads it)
+  if (count_state != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    count_state[1] = count_state[1] + delta;
 
   constexpr int D = FQ_D;
   extern __shared__ __attribute__((aligned(16))) unsigned char fq_lds[];
@@ -436,12 +439,14 @@ bool fold_bf16_applies(int D, int H, int dtype, int w_dtype) {
   return dtype == VQAF_BF16 && w_dtype == VQAF_BF16 && D == FQ_D && H * FQ_DH == D;
 }
 
-int fold_bf16_launch(const FoldSets& sets, int n, int B, int H, hipStream_t st) {
+int fold_bf16_launch(const FoldSets& sets, int n, int B, int H, hipStream_t st, uint64_t* count_state = nullptr,
+                     uint64_t delta = 0) {
   static int attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(fold_query_bf16_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)FQ_LDS);
   if (attr_rc != hipSuccess) return VQAF_E_LAUNCH;
   const dim3 grid((B + FQ_ROWS - 1) / FQ_ROWS, H, n), block(FQ_THREADS);
-  hipLaunchKernelGGL(fold_query_bf16_kernel, grid, block, FQ_LDS, st, sets, B, H);
+  hipLaunchKernelGGL(fold_query_bf16_kernel, grid, block, FQ_LDS, st, sets, B, H,
+                     reinterpret_cast<unsigned long long*>(count_state), (unsigned long long)delta);
   VQAF_LAUNCH_CHECK();
 }
 
@@ -483,9 +488,25 @@ extern "C" int vqaf_gemm_f32_atomic(const void* A, int a_dtype, long a_sg, long 
 
 // u_i (B,H,D) for several (query, in_proj) pairs of one shape: two launches in total (see
 // vqaf_fold_query for the arithmetic).
+static int fold_query_multi(const vqaf_fold_desc* descs_host, int n, int B, int D, int H, int dtype, int w_dtype,
+                            uint64_t* count_state, uint64_t delta, vqaf_stream_t stream);
+
 extern "C" int vqaf_fold_query_multi(const vqaf_fold_desc* descs_host, int n, int B, int D, int H, int dtype,
                                      int w_dtype, vqaf_stream_t stream) {
   VQAF_ENTRY();
+  return fold_query_multi(descs_host, n, B, D, H, dtype, w_dtype, nullptr, 0, stream);
+}
+
+extern "C" int vqaf_fold_query_multi_advance(const vqaf_fold_desc* descs_host, int n, int B, int D, int H, int dtype,
+                                             int w_dtype, uint64_t* count_state, uint64_t delta,
+                                             vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(count_state != nullptr, VQAF_E_NULL);
+  return fold_query_multi(descs_host, n, B, D, H, dtype, w_dtype, count_state, delta, stream);
+}
+
+static int fold_query_multi(const vqaf_fold_desc* descs_host, int n, int B, int D, int H, int dtype, int w_dtype,
+                            uint64_t* count_state, uint64_t delta, vqaf_stream_t stream) {
   VQAF_REQUIRE(descs_host != nullptr, VQAF_E_NULL);
   VQAF_REQUIRE(n > 0 && n <= GEMM_MAX_SETS && B > 0 && D > 0 && H > 0 && D % H == 0, VQAF_E_SHAPE);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype) && vqaf_dtype_ok(w_dtype), VQAF_E_DTYPE);
@@ -504,7 +525,11 @@ extern "C" int vqaf_fold_query_multi(const vqaf_fold_desc* descs_host, int n, in
       fs.qproj[i] = d.qproj_ws;
       fs.u[i] = d.u;
     }
-    return fold_bf16_launch(fs, n, B, H, (hipStream_t)stream);
+    return fold_bf16_launch(fs, n, B, H, (hipStream_t)stream, count_state, delta);
+  }
+  if (count_state != nullptr) {  // the two-launch form has no side job: the count takes its own launch
+    const int rc = vqaf_rng_advance(count_state, delta, stream);
+    if (rc != VQAF_OK) return rc;
   }
   const int dh = D / H;
   const size_t esz = vqaf_esize(w_dtype);

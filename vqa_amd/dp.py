@@ -486,6 +486,7 @@ class DPOptimizer:
         # GEMM (56 + 7 us against 31 + 30 us for the two launches at batch 1024), so nothing is gained yet.
         self.fuse_update_into_sums = False
         self._updated = None
+        self._step_counted = False
         self.last_norms = None
         self._last_coef, self._last_scale = None, 1.0
 
@@ -629,6 +630,7 @@ class DPOptimizer:
         else:
             src, std, scale, noise = grad, 0.0, 1.0, None
         single = len(self.original_optimizer.param_groups) == 1
+        counted, self._step_counted = self._step_counted, False  # the clipping launch already counted this step
         if self._updated:
             # the clipped-sum launch already updated the Linear layers: the rest (normalisation layers) in
             # one launch over their ranges, with the noise addressing of the whole-bucket launch
@@ -665,12 +667,14 @@ class DPOptimizer:
                                     ptr(self._P[lo:hi]), ptr(self._M[lo:hi]), ptr(self._V[lo:hi]),
                                     ptr(self._shadow[lo:hi]), ptr(grad[lo:hi]), hi - lo, float(group["lr"]),
                                     float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                    ptr(self._step), 0, st), "vqaf_dp_adamw")
+                                    ptr(self._step), -1 if counted else 0, st), "vqaf_dp_adamw")
             if world == 1 and nz is None and std != 0.0 and not single:
                 self._rng.advance()  # several groups: a fresh stream for the next group / step
         # (step_advance = 1 would count the step in the kernel, but its returning device-scope atomic per
-        # workgroup costs more than this one-thread launch at 4096 short workgroups)
-        check(lib.vqaf_rng_advance(ptr(self._step), 1, st), "vqaf_rng_advance")
+        # workgroup costs more than a one-thread launch at 4096 short workgroups; the clipping launch of
+        # local_step() counts the step on the side instead, and only a step without one pays this launch)
+        if not counted:
+            check(lib.vqaf_rng_advance(ptr(self._step), 1, st), "vqaf_rng_advance")
         self.module.step_counter = self._step
         self.module._drop_calls = 0
 
@@ -688,11 +692,14 @@ class DPOptimizer:
         return buf[o:o + p.numel()]
 
     @torch.no_grad()
-    def clip_and_accumulate(self, fuse_update: bool = False):
+    def clip_and_accumulate(self, fuse_update: bool = False, count_step: bool = False):
         """Fills the flat clipped-sum buffer from the layer tapes; returns it.  With fuse_update the launch
         that forms the Linear layers' sums also applies their noise + AdamW update (those slices of the
-        buffer are then not written; self._updated names the parameters)."""
+        buffer are then not written; self._updated names the parameters).  With count_step the clipping
+        launch also advances the device-side update count that the fused update reads (self._step_counted
+        tells _fused_apply so): the step then spends no launch of its own on the count."""
         self._updated = None
+        self._step_counted = False
         tapes = [t for t in self.module.tapes if t.g is not None]
         if not tapes:
             raise RuntimeError("DPOptimizer.step() called before loss.backward()")
@@ -752,9 +759,12 @@ class DPOptimizer:
             nz = len(zero) if len(zero) <= 8 else 0
             zp = (ctypes.c_void_p * max(nz, 1))(*[ptr(z) for z in zero[:nz]])
             zn = (ctypes.c_size_t * max(nz, 1))(*[z.numel() for z in zero[:nz]])
-            check(lib.vqaf_ghost_clip_zero(n, pa, pg, din, dout, kind, B, dtype_code(tapes[0].g),
-                                           max_norm, scale, 1, ptr(coef), ptr(norms), None, zp, zn, nz, st),
-                  "vqaf_ghost_clip_zero")
+            count_step = count_step and self._step is not None and not fuse_update
+            check(lib.vqaf_ghost_clip_zero_bump(n, pa, pg, din, dout, kind, B, dtype_code(tapes[0].g),
+                                                max_norm, scale, 1, ptr(coef), ptr(norms), None, zp, zn, nz,
+                                                ptr(self._step) if count_step else None, st),
+                  "vqaf_ghost_clip_zero_bump")
+            self._step_counted = count_step
             prescaled = True
             pre_zeroed = nz > 0
         else:
@@ -916,7 +926,12 @@ class DPOptimizer:
                 self._buffers(tapes[0].g.device)
                 self._fused_buffers(tapes[0].g.device)
                 fuse_update = True
-        self.clip_and_accumulate(fuse_update=fuse_update)
+        if self._use_fused:
+            tapes = [t for t in self.module.tapes if t.g is not None]
+            if tapes:
+                self._buffers(tapes[0].g.device)
+                self._fused_buffers(tapes[0].g.device)  # the update count lives there
+        self.clip_and_accumulate(fuse_update=fuse_update, count_step=self._use_fused)
         if not (self._use_fused and world == 1):
             self._noise_scale_local(noise)
 

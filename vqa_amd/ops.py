@@ -54,6 +54,7 @@ def default_rng(device: torch.device) -> PhiloxState:
     return st[1]
 
 
+ADVANCE_RNG_IN_FOLD = True  # the query-fold launch of fused_prune_pool advances the generator state on the side
 IN_KERNEL_RNG_BUMP = False  # let vqaf_fused_prune_pool_multi advance its generator state itself
 FUSED_ONE_PASS = False  # True: the one-launch pruning branch takes the one-pass kernel where it applies (D = 512, N <= 208)
 
@@ -587,8 +588,15 @@ class _FusedPrunePool(torch.autograd.Function):
                                       and noise_state.data_ptr() == rng_state.data_ptr()))
             idxs.append(idx)
             metas.append((N, int(k), D, float(alpha), seq.dtype, i * D))
-        check(lib.vqaf_fold_query_multi(ctypes.cast(folds, ctypes.c_void_p), n_mod, B, D, H, dtype_code(seq0),
-                                        _lib.BF16 if w_dt == torch.bfloat16 else _lib.F32, st), "vqaf_fold_query_multi")
+        if rng_advance < 0:  # the fold launch advances the generator state for the launch behind it
+            check(lib.vqaf_fold_query_multi_advance(ctypes.cast(folds, ctypes.c_void_p), n_mod, B, D, H,
+                                                    dtype_code(seq0), _lib.BF16 if w_dt == torch.bfloat16 else _lib.F32,
+                                                    ptr(rng_state), -int(rng_advance), st),
+                  "vqaf_fold_query_multi_advance")
+        else:
+            check(lib.vqaf_fold_query_multi(ctypes.cast(folds, ctypes.c_void_p), n_mod, B, D, H, dtype_code(seq0),
+                                            _lib.BF16 if w_dt == torch.bfloat16 else _lib.F32, st),
+                  "vqaf_fold_query_multi")
         _probe("fused_prune_pool", "begin")
         entry = lib.vqaf_fused_prune_pool_multi
         if FUSED_ONE_PASS:
@@ -661,11 +669,15 @@ def fused_prune_pool(specs, out_dtype: torch.dtype, rng: Optional["PhiloxState"]
     streams = list(noise_states) + ([rng.state] if drew else [])
     # (off by default: the bump costs every workgroup a returning device-scope atomic at its end, which
     # at thousands of workgroups per launch is slower than the one-thread launch it saves)
-    in_kernel = IN_KERNEL_RNG_BUMP and bool(streams) and streams[0].numel() >= 4 and \
-        all(t.data_ptr() == streams[0].data_ptr() for t in streams)
-    res = _FusedPrunePool.apply(len(specs), out_dtype, streams[0] if in_kernel else (rng.state if drew else None),
-                                len(streams) if in_kernel else 0, drew, *flat)
-    return res[0], list(res[1:]), drew and not in_kernel
+    one_state = bool(streams) and all(t.data_ptr() == streams[0].data_ptr() for t in streams)
+    in_kernel = IN_KERNEL_RNG_BUMP and one_state and streams[0].numel() >= 4
+    # (the default) the query-fold launch in front of the token launch advances the counter on the side, and
+    # the token launch draws from the positions in front of the advance: same values, no counter launch
+    ahead = ADVANCE_RNG_IN_FOLD and one_state and not in_kernel
+    res = _FusedPrunePool.apply(len(specs), out_dtype,
+                                streams[0] if (in_kernel or ahead) else (rng.state if drew else None),
+                                len(streams) if in_kernel else (-len(streams) if ahead else 0), drew, *flat)
+    return res[0], list(res[1:]), drew and not (in_kernel or ahead)
 
 
 def pruned_pool(mods, out_dtype: torch.dtype) -> torch.Tensor:
