@@ -392,6 +392,54 @@ int vqaf_gemm_f32_atomic(const void* A, int a_dtype, long a_sg, long a_sm, long 
                   long bias_sg, float* C, long c_sg, long c_sm, int G, int M, int N, int K,
                   float alpha, int beta_one, vqaf_stream_t stream);
 
+/* vqaf_gemm_f32_atomic for n_sets <= 4 problems of ONE shape, stride set and dtype set in one launch (HOST
+ * arrays of n_sets device pointers; bias_host may be NULL or hold NULLs): the two attention branches of
+ * CoAttention (utils/fusion.py:257-268) have equal-shaped projections, which then share their launches. */
+int vqaf_gemm_f32_atomic_sets(int n_sets, const void* const* A_host, int a_dtype, long a_sg, long a_sm,
+                              long a_sk, const void* const* Bm_host, int b_dtype, long b_sg, long b_sk,
+                              long b_sn, const void* const* bias_host, int bias_dtype, long bias_sg,
+                              float* const* C_host, long c_sg, long c_sm, int G, int M, int N, int K,
+                              float alpha, int beta_one, vqaf_stream_t stream);
+
+/* Both branches of the dense co-attention (utils/fusion.py:257-268) in the same launches, with the
+ * per-sample softmax steps fused into the token passes; n <= 4 problems of one batch size, width and head
+ * count, each with its own token count and buffers.  Results are bit-identical to the separate launches
+ * (vqaf_softmax_heads + vqaf_weighted_token_sum; vqaf_softmax_heads_bwd + vqaf_weighted_token_sum +
+ * vqaf_token_outer): same arithmetic, same order of every sum.
+ *   vqaf_softmax_wsum_multi:  p[b,h,n] = softmax_n s[b,n,h] (written out for the backward),
+ *                             z[b,h,:] = sum_n p[b,h,n] x_bn
+ *   vqaf_token_bwd_multi:     ds = p * (dp - sum_n p dp) (kept on chip),  du[b,h,:] = sum_n ds[b,h,n] x_bn,
+ *                             grad_seq[b,n,:] = sum_h ds[b,h,n] u[b,h,:] + p[b,h,n] t[b,h,:]
+ * du or grad_seq may be NULL (for every problem alike) when that gradient is not needed.  H <= 8,
+ * D % 8 == 0, and the per-sample coefficients must fit 128 KiB of LDS (H*N*4, resp. 2*H*N*4 bytes + 8 KiB). */
+typedef struct vqaf_dense_fwd_mod {
+  const void* seq; /* (B,N,D) `dtype` */
+  const float* s;  /* (B,N,H) raw head scores */
+  float* p;        /* (B,H,N) out */
+  float* z;        /* (B,H,D) out */
+  int N;
+} vqaf_dense_fwd_mod;
+int vqaf_softmax_wsum_multi(const vqaf_dense_fwd_mod* mods_host, int n, int B, int D, int H, int dtype,
+                            vqaf_stream_t stream);
+typedef struct vqaf_dense_bwd_mod {
+  const void* seq; /* (B,N,D) `dtype` */
+  const float* p;  /* (B,H,N) */
+  const float* dp; /* (B,N,H) = seq . t */
+  const float* u;  /* (B,H,D) folded queries */
+  const float* t;  /* (B,H,D) = Wv_h^T d_attn_h */
+  float* du;       /* (B,H,D) out or NULL */
+  void* grad_seq;  /* (B,N,D) `dtype` out or NULL */
+  int N;
+} vqaf_dense_bwd_mod;
+int vqaf_token_bwd_multi(const vqaf_dense_bwd_mod* mods_host, int n, int B, int D, int H, int dtype,
+                         vqaf_stream_t stream);
+
+/* dst_i[c] += sum_r src_i[r * ld_i + c], c < cols, r < rows, for n <= 8 (source, destination) pairs in one
+ * launch (sources f32 or bf16; destinations f32, zeroed by the caller; f32 atomics across row blocks): the
+ * bias gradients of the attention modules' projections (utils/fusion.py:194-200 under autograd). */
+int vqaf_colsum_multi(int n, const void* const* src_host, const int* src_dtype_host, const long* ld_host,
+                      float* const* dst_host, int rows, int cols, vqaf_stream_t stream);
+
 /* bf16 GEMM on the matrix cores for the classifier's three uses of a Linear under DP-SGD
  * (model/model.py:54-63 wrapped at train.py:124-141):
  *   C[m][n] = sum_k A(m,k) B(k,n) (+ bias[n]),   f32 accumulation,

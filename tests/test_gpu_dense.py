@@ -26,8 +26,10 @@ def _close(got, want, rtol=1e-4, atol_rel=1e-5):
     np.testing.assert_allclose(np.asarray(got), want, rtol=rtol, atol=atol_rel * max(1e-12, np.abs(want).max()))
 
 
+@pytest.mark.parametrize("batched", [True, False])
 @pytest.mark.parametrize("name", ["coattn_N49", "coattn_N197", "coattn_N577"])
-def test_coattention_dense_vs_golden(dev, name):
+def test_coattention_dense_vs_golden(dev, name, batched):
+    """batched: both branches in the same launches (the default); else one chain of launches per branch."""
     from vqa_amd import fusion
     g = load_golden(name)
     seed, B, N = int(g["seed"]), int(g["B"]), int(g["N"])
@@ -38,6 +40,7 @@ def test_coattention_dense_vs_golden(dev, name):
     m.txt_to_vis_attn.load_state_dict(gi.mha_params(seed + 2))
     m.vis_to_txt_attn.load_state_dict(gi.mha_params(seed + 6))
     m = m.to(dev)
+    m.batch_branches = batched
     vs, qs = v_seq.to(dev).requires_grad_(), q_seq.to(dev).requires_grad_()
     vg, qg = v_global.to(dev).requires_grad_(), q_global.to(dev).requires_grad_()
     out = m(vs, vg, qs, qg)
@@ -97,3 +100,125 @@ def getattr_path(mod, path):
     for part in path.split("."):
         mod = getattr(mod, part)
     return mod
+
+
+@pytest.mark.parametrize("B,Nv,Nq,dtype,need_globals", [(5, 197, 30, torch.bfloat16, True), (64, 197, 30, torch.bfloat16, False),
+                                                        (3, 577, 12, torch.bfloat16, True), (4, 50, 77, torch.float32, True),
+                                                        (2, 900, 30, torch.bfloat16, False)])
+def test_batched_branches_equal_the_per_branch_launches(dev, B, Nv, Nq, dtype, need_globals):
+    """CoAttention without pruning: both branches in the same launches against one chain of launches per
+    branch.  The token kernels share their arithmetic and summation order, so the token gradients are
+    bit-identical given the same coefficients; the (B,E)-sized products are split over workgroups with f32
+    atomics in both forms, so everything downstream of them agrees to f32 rounding."""
+    from vqa_amd import fusion
+    torch.manual_seed(5)
+    m = fusion.CoAttention(use_pruning=False).to(dev).to(dtype)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    v = torch.randn(B, Nv, 512, device=dev, generator=gen).to(dtype)
+    q = torch.randn(B, Nq, 512, device=dev, generator=gen).to(dtype)
+    vg = torch.randn(B, 512, device=dev, generator=gen).to(dtype)
+    qg = torch.randn(B, 512, device=dev, generator=gen).to(dtype)
+    cot = torch.randn(B, 1024, device=dev, generator=gen)
+    res = []
+    for batched in (True, False):
+        m.batch_branches = batched
+        m.zero_grad(set_to_none=True)
+        ins = [t.clone().requires_grad_(need_globals or i % 2 == 0) for i, t in enumerate((v, vg, q, qg))]
+        out = m(*ins)
+        assert out.dtype == dtype and out.shape == (B, 1024)
+        (out.float() * cot).sum().backward()
+        res.append((out.detach().float(), [None if t.grad is None else t.grad.float() for t in ins],
+                    {n: p.grad.float() for n, p in m.named_parameters()}))
+    (oa, ia, pa), (ob, ib, pb) = res
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+
+    def close(a, b, what):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= tol * scale, what
+
+    close(oa, ob, "output")
+    for i, (a, b) in enumerate(zip(ia, ib)):
+        assert (a is None) == (b is None)
+        if a is not None:
+            close(a, b, f"input gradient {i}")
+    assert pa.keys() == pb.keys()
+    for n in pa:
+        close(pa[n], pb[n], n)
+    for n in ("txt_to_vis_attn.in_proj_bias", "vis_to_txt_attn.in_proj_bias"):  # key bias: exactly zero
+        assert float(pa[n][512:1024].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("H", [8, 4, 3])
+def test_fused_token_kernels_are_bit_identical_to_the_separate_launches(dev, dtype, H):
+    """vqaf_softmax_wsum_multi / vqaf_token_bwd_multi / vqaf_colsum_multi / vqaf_gemm_f32_atomic_sets through
+    the C ABI against the launches they replace, two problems of different token counts per launch."""
+    import ctypes
+    from vqa_amd import _lib
+    from vqa_amd._lib import check, dtype_code, load, ptr, stream_ptr
+    lib, st = load(), stream_ptr(dev)
+    B, D, Ns = 6, 256, (77, 301)
+    gen = torch.Generator(device=dev).manual_seed(17)
+    f32 = dict(dtype=torch.float32, device=dev)
+    seqs = [torch.randn(B, n, D, device=dev, generator=gen).to(dtype) for n in Ns]
+    ss = [torch.randn(B, n, H, device=dev, generator=gen) * 3 for n in Ns]
+    us = [torch.randn(B, H, D, device=dev, generator=gen) for _ in Ns]
+    ts = [torch.randn(B, H, D, device=dev, generator=gen) for _ in Ns]
+    dps = [torch.randn(B, n, H, device=dev, generator=gen) for n in Ns]
+    # forward
+    p1 = [torch.empty(B, H, n, **f32) for n in Ns]
+    z1 = [torch.empty(B, H, D, **f32) for _ in Ns]
+    fm = (_lib.DenseFwdMod * 2)(*[_lib.DenseFwdMod(ptr(seqs[i]), ptr(ss[i]), ptr(p1[i]), ptr(z1[i]), Ns[i]) for i in range(2)])
+    check(lib.vqaf_softmax_wsum_multi(ctypes.cast(fm, ctypes.c_void_p), 2, B, D, H, dtype_code(seqs[0]), st), "fwd")
+    for i, n in enumerate(Ns):
+        p0, z0 = torch.empty(B, H, n, **f32), torch.empty(B, H, D, **f32)
+        check(lib.vqaf_softmax_heads(ptr(ss[i]), B, n, H, ptr(p0), st), "softmax")
+        check(lib.vqaf_weighted_token_sum(ptr(seqs[i]), ptr(p0), B, n, D, H, dtype_code(seqs[i]), ptr(z0), st), "wsum")
+        assert torch.equal(p0, p1[i]) and torch.equal(z0, z1[i])
+    # backward, every combination of requested outputs
+    for need_u, need_seq in ((True, True), (False, True), (True, False)):
+        du1 = [torch.empty(B, H, D, **f32) if need_u else None for _ in Ns]
+        gs1 = [torch.empty_like(s) if need_seq else None for s in seqs]
+        bm = (_lib.DenseBwdMod * 2)(*[_lib.DenseBwdMod(ptr(seqs[i]), ptr(p1[i]), ptr(dps[i]), ptr(us[i]), ptr(ts[i]),
+                                                       ptr(du1[i]), ptr(gs1[i]), Ns[i]) for i in range(2)])
+        check(lib.vqaf_token_bwd_multi(ctypes.cast(bm, ctypes.c_void_p), 2, B, D, H, dtype_code(seqs[0]), st), "bwd")
+        for i, n in enumerate(Ns):
+            ds0 = torch.empty(B, H, n, **f32)
+            check(lib.vqaf_softmax_heads_bwd(ptr(p1[i]), ptr(dps[i]), B, n, H, ptr(ds0), st), "softmax_bwd")
+            if need_u:
+                du0 = torch.empty(B, H, D, **f32)
+                check(lib.vqaf_weighted_token_sum(ptr(seqs[i]), ptr(ds0), B, n, D, H, dtype_code(seqs[i]), ptr(du0), st), "du")
+                assert torch.equal(du0, du1[i])
+            if need_seq:
+                g0 = torch.empty_like(seqs[i])
+                check(lib.vqaf_token_outer(ptr(ds0), ptr(us[i]), ptr(p1[i]), ptr(ts[i]), B, n, D, H, dtype_code(g0),
+                                           ptr(g0), st), "outer")
+                assert torch.equal(g0, gs1[i])
+    # mixed requests across problems are refused, as is a launch with nothing to write
+    bm = (_lib.DenseBwdMod * 2)(*[_lib.DenseBwdMod(ptr(seqs[i]), ptr(p1[i]), ptr(dps[i]), ptr(us[i]), ptr(ts[i]),
+                                                   ptr(z1[i]) if i == 0 else None, None, Ns[i]) for i in range(2)])
+    assert lib.vqaf_token_bwd_multi(ctypes.cast(bm, ctypes.c_void_p), 2, B, D, H, dtype_code(seqs[0]), st) != 0
+    # column sums: f32 and bf16 sources, a pitch wider than the summed columns
+    rows, cols = 700, 200
+    a = torch.randn(rows, 2 * cols, device=dev, generator=gen).to(dtype)
+    b_ = torch.randn(rows, cols, device=dev, generator=gen)
+    dst = torch.zeros(3, cols, **f32)
+    srcs = [(a, 0, 2 * cols), (a, cols, 2 * cols), (b_, 0, cols)]
+    check(lib.vqaf_colsum_multi(3, (ctypes.c_void_p * 3)(*[t.data_ptr() + o * t.element_size() for t, o, _ in srcs]),
+                                (ctypes.c_int * 3)(*[dtype_code(t) for t, _, _ in srcs]),
+                                (ctypes.c_long * 3)(*[ld for _, _, ld in srcs]),
+                                (ctypes.c_void_p * 3)(*[ptr(dst[i]) for i in range(3)]), rows, cols, st), "colsum")
+    want = torch.stack([a[:, :cols].double().sum(0), a[:, cols:].double().sum(0), b_.double().sum(0)])
+    assert float((dst.double() - want).abs().max()) < 1e-3
+    # two equal-shaped products in one launch against one launch each
+    M, N, K = 40, 96, 512
+    As = [torch.randn(M, K, device=dev, generator=gen) for _ in range(2)]
+    Bs = [torch.randn(K, N, device=dev, generator=gen) for _ in range(2)]
+    C = torch.zeros(2, M, N, **f32)
+    vp = ctypes.c_void_p * 2
+    check(lib.vqaf_gemm_f32_atomic_sets(2, vp(*[ptr(x) for x in As]), _lib.F32, 0, K, 1, vp(*[ptr(x) for x in Bs]), _lib.F32,
+                                        0, N, 1, None, _lib.F32, 0, vp(ptr(C[0]), ptr(C[1])), 0, N, 1, M, N, K, 0.5, 1, st),
+          "gemm sets")
+    for i in range(2):
+        want = 0.5 * As[i].double() @ Bs[i].double()
+        assert float((C[i].double() - want).abs().max()) < 1e-3

@@ -55,6 +55,17 @@ class FusedMod(ctypes.Structure):
                 ("adv_mode", c_int), ("k_adv", c_int), ("col0", c_int), ("noise_counter_offset", c_int)]
 
 
+class DenseFwdMod(ctypes.Structure):
+    """vqaf_dense_fwd_mod of include/vqaf.h."""
+    _fields_ = [("seq", c_void_p), ("s", c_void_p), ("p", c_void_p), ("z", c_void_p), ("N", c_int)]
+
+
+class DenseBwdMod(ctypes.Structure):
+    """vqaf_dense_bwd_mod of include/vqaf.h."""
+    _fields_ = [("seq", c_void_p), ("p", c_void_p), ("dp", c_void_p), ("u", c_void_p), ("t", c_void_p),
+                ("du", c_void_p), ("grad_seq", c_void_p), ("N", c_int)]
+
+
 class PoolBwdMod(ctypes.Structure):
     """vqaf_pool_bwd_mod of include/vqaf.h."""
     _fields_ = [("idx", c_void_p), ("grad_seq", c_void_p), ("alpha", c_float), ("N", c_int), ("K", c_int),
@@ -111,6 +122,12 @@ SIGNATURES = {
     "vqaf_gemm_f32_atomic": (c_int, [_P, c_int, c_long, c_long, c_long, _P, c_int, c_long, c_long, c_long,
                                      _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
                                      c_float, c_int, _P]),
+    "vqaf_gemm_f32_atomic_sets": (c_int, [c_int, _P, c_int, c_long, c_long, c_long, _P, c_int, c_long, c_long, c_long,
+                                          _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
+                                          c_float, c_int, _P]),
+    "vqaf_softmax_wsum_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vqaf_token_bwd_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vqaf_colsum_multi": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, _P]),
     "vqaf_gemm_bf16_supported": (c_int, [c_long, c_int, c_long, c_int, c_int, c_int, c_int]),
     "vqaf_clipped_sum_adamw_group": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_long, _P, c_float, c_float,
                                              _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),

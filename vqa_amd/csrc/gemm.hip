@@ -486,6 +486,26 @@ extern "C" int vqaf_gemm_f32_atomic(const void* A, int a_dtype, long a_sg, long 
                      c_sm, G, M, N, K, alpha, beta_one, (hipStream_t)stream, true);
 }
 
+extern "C" int vqaf_gemm_f32_atomic_sets(int n_sets, const void* const* A_host, int a_dtype, long a_sg, long a_sm,
+                                         long a_sk, const void* const* Bm_host, int b_dtype, long b_sg, long b_sk,
+                                         long b_sn, const void* const* bias_host, int bias_dtype, long bias_sg,
+                                         float* const* C_host, long c_sg, long c_sm, int G, int M, int N, int K,
+                                         float alpha, int beta_one, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(A_host != nullptr && Bm_host != nullptr && C_host != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(n_sets > 0 && n_sets <= GEMM_MAX_SETS, VQAF_E_SHAPE);
+  GemmSets sets = {};
+  for (int i = 0; i < n_sets; ++i) {
+    sets.A[i] = A_host[i];
+    sets.Bm[i] = Bm_host[i];
+    sets.bias[i] = bias_host != nullptr ? bias_host[i] : nullptr;
+    sets.C[i] = C_host[i];
+  }
+  sets.gper = G;
+  return gemm_launch(sets, n_sets, a_dtype, a_sg, a_sm, a_sk, b_dtype, b_sg, b_sk, b_sn, bias_dtype, bias_sg, c_sg,
+                     c_sm, G, M, N, K, alpha, beta_one, (hipStream_t)stream, true);
+}
+
 // u_i (B,H,D) for several (query, in_proj) pairs of one shape: two launches in total (see
 // vqaf_fold_query for the arithmetic).
 static int fold_query_multi(const vqaf_fold_desc* descs_host, int n, int B, int D, int H, int dtype, int w_dtype,

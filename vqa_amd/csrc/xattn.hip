@@ -243,6 +243,268 @@ token_outer_kernel(const float* __restrict__ ca, const float* __restrict__ va,
   }
 }
 
+// ---- Both attention branches of a dense co-attention in the same launches ------------------------
+// The kernels below take up to XA_MAX_MODS problems of one batch size and width (different token counts
+// and buffers; blockIdx.z picks the problem) and fuse the per-sample softmax steps into the token passes:
+//   softmax_wsum_multi_kernel   s -> p (written once, by the first column slice) and z = sum_n p x
+//   token_bwd_multi_kernel      (p, dp) -> ds in LDS, du = sum_n ds x and grad_seq = ds u + p t, one pass
+// The arithmetic and the order of every sum are those of softmax_heads(_bwd)_kernel,
+// weighted_token_sum_kernel and token_outer_kernel, so the results are bit-identical to the separate launches.
+constexpr int XA_MAX_MODS = 4;
+struct XaFwdMod {
+  const void* seq;  // (B,N,D)
+  const float* s;   // (B,N,H) raw scores
+  float* p;         // (B,H,N) out
+  float* z;         // (B,H,D) out
+  int N;
+};
+struct XaFwdMods { XaFwdMod m[XA_MAX_MODS]; };
+struct XaBwdMod {
+  const void* seq;  // (B,N,D)
+  const float* p;   // (B,H,N)
+  const float* dp;  // (B,N,H)
+  const float* u;   // (B,H,D)
+  const float* t;   // (B,H,D)
+  float* du;        // (B,H,D) out or NULL
+  void* gseq;       // (B,N,D) out or NULL
+  int N;
+};
+struct XaBwdMods { XaBwdMod m[XA_MAX_MODS]; };
+
+// Fixed-order reduction over the workgroup of HP per-thread values: wave, then waves in index order.
+template <int HP, bool MAX>
+__device__ __forceinline__ void xa_block_reduce(float (&v)[HP], float (*red)[HP], float* stat) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int h = 0; h < HP; ++h) {
+    const float r = MAX ? wave_max(v[h]) : wave_sum(v[h]);
+    if (lane == 0) red[wave][h] = r;
+  }
+  __syncthreads();
+  if (tid < HP) {
+    float r = red[0][tid];
+    for (int i = 1; i < XA_THREADS / 64; ++i) r = MAX ? fmaxf(r, red[i][tid]) : r + red[i][tid];
+    stat[tid] = r;
+  }
+  __syncthreads();
+}
+
+// The weighted-sum pass of weighted_token_sum_kernel over coefficients already token-major in LDS
+// (cs[n * CP + h], h < HP) and its fixed-order fold into z[b,h,slice].
+template <bool BF16, int HP, int CP>
+__device__ __forceinline__ void xa_weighted_sum(const void* __restrict__ seq, const float* cs, float* red, int b,
+                                                int N, int D, int H, float* __restrict__ z) {
+  constexpr int U = 4;
+  const int tid = threadIdx.x, g = tid / XA_LPR, li = tid % XA_LPR;
+  const int d0 = blockIdx.x * XA_SLW + li * 8;
+  float acc[HP][8];
+#pragma unroll
+  for (int h = 0; h < HP; ++h)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[h][i] = 0.f;
+  if (d0 < D) {
+    for (int n0 = g; n0 < N; n0 += U * XA_ROWS) {
+      float x[U][8];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        load8<BF16>(seq, ((size_t)b * N + min(n0 + u * XA_ROWS, N - 1)) * D + d0, x[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int n = n0 + u * XA_ROWS;
+        const bool in = n < N;
+        const float* cw = cs + (size_t)min(n, N - 1) * CP;
+        float w[HP];
+        if constexpr (HP >= 4) {
+#pragma unroll
+          for (int h = 0; h < HP; h += 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(cw + h);
+            w[h] = q.x; w[h + 1] = q.y; w[h + 2] = q.z; w[h + 3] = q.w;
+          }
+        } else {
+#pragma unroll
+          for (int h = 0; h < HP; ++h) w[h] = cw[h];
+        }
+#pragma unroll
+        for (int h = 0; h < HP; ++h) {
+          const float wh = in ? w[h] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[h][i] = fmaf(wh, x[u][i], acc[h][i]);
+        }
+      }
+    }
+  }
+  for (int h = 0; h < H; ++h) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = 0.f;
+#pragma unroll
+      for (int hh = 0; hh < HP; ++hh) v = (hh == h) ? acc[hh][i] : v;
+      red[tid * 8 + i] = v;
+    }
+    __syncthreads();
+    if (tid < XA_SLW) {
+      float v = 0.f;
+      for (int gg = 0; gg < XA_ROWS; ++gg) v += red[(gg * XA_LPR + tid / 8) * 8 + (tid & 7)];
+      const int d = blockIdx.x * XA_SLW + tid;
+      if (d < D) z[((size_t)b * H + h) * D + d] = v;
+    }
+  }
+}
+
+template <bool BF16, int HP>
+__global__ void __launch_bounds__(XA_THREADS)
+softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H) {
+  extern __shared__ __attribute__((aligned(16))) float xsm[];
+  const XaFwdMod& M = mods.m[blockIdx.z];
+  const int N = M.N, b = blockIdx.y, tid = threadIdx.x;
+  float* cs = xsm;                                  // [N][HP]
+  float* red = xsm + (size_t)HP * N;                // [XA_THREADS * 8]
+  float (*wred)[HP] = reinterpret_cast<float (*)[HP]>(red);  // the block reductions run before the sums use it
+  float* stat = red + XA_THREADS * 8;               // [2][HP]
+  const float* sb = M.s + (size_t)b * N * H;
+  float m[HP], zz[HP];
+#pragma unroll
+  for (int h = 0; h < HP; ++h) { m[h] = -INFINITY; zz[h] = 0.f; }
+  for (int n = tid; n < N; n += XA_THREADS)
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+      const float v = h < H ? sb[(size_t)n * H + h] : 0.f;
+      cs[n * HP + h] = v;
+      if (h < H) m[h] = fmaxf(m[h], v);
+    }
+  xa_block_reduce<HP, true>(m, wred, stat);
+#pragma unroll
+  for (int h = 0; h < HP; ++h) m[h] = stat[h];
+  __syncthreads();  // stat is rewritten below
+  for (int n = tid; n < N; n += XA_THREADS)
+#pragma unroll
+    for (int h = 0; h < HP; ++h)
+      if (h < H) zz[h] += expf(cs[n * HP + h] - m[h]);
+  xa_block_reduce<HP, false>(zz, wred, stat + HP);
+  float* pb = M.p + (size_t)b * H * N;
+  for (int n = tid; n < N; n += XA_THREADS)
+#pragma unroll
+    for (int h = 0; h < HP; ++h)
+      if (h < H) {
+        const float pv = expf(cs[n * HP + h] - m[h]) / stat[HP + h];
+        cs[n * HP + h] = pv;
+        if (blockIdx.x == 0) pb[(size_t)h * N + n] = pv;
+      }
+  __syncthreads();
+  xa_weighted_sum<BF16, HP, HP>(M.seq, cs, red, b, N, D, H, M.z);
+}
+
+template <bool BF16, int HP, bool NEED_U, bool NEED_SEQ>
+__global__ void __launch_bounds__(XA_THREADS)
+token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
+  extern __shared__ __attribute__((aligned(16))) float xsm[];
+  const XaBwdMod& M = mods.m[blockIdx.z];
+  const int N = M.N, b = blockIdx.y, tid = threadIdx.x, g = tid / XA_LPR, li = tid % XA_LPR;
+  float* cs = xsm;                                  // [N][2*HP]: ds_0..ds_{HP-1}, p_0..p_{HP-1}
+  float* red = xsm + (size_t)2 * HP * N;            // [XA_THREADS * 8]
+  float (*wred)[HP] = reinterpret_cast<float (*)[HP]>(red);
+  float* stat = red + XA_THREADS * 8;               // [HP]
+  const float* pb = M.p + (size_t)b * H * N;
+  const float* dpb = M.dp + (size_t)b * N * H;
+  float acc[HP];
+#pragma unroll
+  for (int h = 0; h < HP; ++h) acc[h] = 0.f;
+  for (int n = tid; n < N; n += XA_THREADS)
+#pragma unroll
+    for (int h = 0; h < HP; ++h) {
+      const float pv = h < H ? pb[(size_t)h * N + n] : 0.f;
+      const float dv = h < H ? dpb[(size_t)n * H + h] : 0.f;
+      cs[n * 2 * HP + HP + h] = pv;
+      cs[n * 2 * HP + h] = dv;
+      if (h < H) acc[h] = fmaf(pv, dv, acc[h]);
+    }
+  xa_block_reduce<HP, false>(acc, wred, stat);
+  for (int n = tid; n < N; n += XA_THREADS)
+#pragma unroll
+    for (int h = 0; h < HP; ++h)
+      if (h < H) cs[n * 2 * HP + h] = cs[n * 2 * HP + HP + h] * (cs[n * 2 * HP + h] - stat[h]);
+  __syncthreads();
+  if constexpr (NEED_SEQ) {
+    const int d0 = blockIdx.x * XA_SLW + li * 8;
+    if (d0 < D) {
+      float ra[HP][8], rb[HP][8];
+#pragma unroll
+      for (int h = 0; h < HP; ++h) {
+        if (h < H) {
+          load8<false>(M.u, ((size_t)b * H + h) * D + d0, ra[h]);
+          load8<false>(M.t, ((size_t)b * H + h) * D + d0, rb[h]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ra[h][i] = rb[h][i] = 0.f;
+        }
+      }
+      auto row = [&](int n, float (&o)[8]) {
+        const float* cw = cs + (size_t)n * 2 * HP;
+        float w[2 * HP];
+        if constexpr (HP >= 2) {
+#pragma unroll
+          for (int h = 0; h < 2 * HP; h += 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(cw + h);
+            w[h] = q.x; w[h + 1] = q.y; w[h + 2] = q.z; w[h + 3] = q.w;
+          }
+        } else {
+          w[0] = cw[0]; w[1] = cw[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+#pragma unroll
+        for (int h = 0; h < HP; ++h)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = fmaf(w[h], ra[h][i], fmaf(w[HP + h], rb[h][i], o[i]));
+      };
+      int n = g;
+      for (; n + XA_ROWS < N; n += 2 * XA_ROWS) {
+        float o0[8], o1[8];
+        row(n, o0);
+        row(n + XA_ROWS, o1);
+        store8<BF16>(M.gseq, ((size_t)b * N + n) * D + d0, o0);
+        store8<BF16>(M.gseq, ((size_t)b * N + n + XA_ROWS) * D + d0, o1);
+      }
+      if (n < N) {
+        float o0[8];
+        row(n, o0);
+        store8<BF16>(M.gseq, ((size_t)b * N + n) * D + d0, o0);
+      }
+    }
+  }
+  if constexpr (NEED_U) xa_weighted_sum<BF16, HP, 2 * HP>(M.seq, cs, red, b, N, D, H, M.du);
+}
+
+// dst[c] += sum_r src[r * ld + c] for up to XA_MAX_COLSUMS (source, destination) pairs in one launch (f32 or
+// bf16 sources; the destinations start from zero): the bias gradients of the dense branch.
+constexpr int XA_MAX_COLSUMS = 8;
+constexpr int XA_COLSUM_ROWS = 256;
+struct XaColsums {
+  const void* src[XA_MAX_COLSUMS];
+  float* dst[XA_MAX_COLSUMS];
+  long ld[XA_MAX_COLSUMS];
+  int bf16[XA_MAX_COLSUMS];
+};
+__global__ void __launch_bounds__(XA_THREADS)
+colsum_multi_kernel(XaColsums P, int rows, int cols) {
+  __shared__ float red[4][64];
+  const int k = blockIdx.z;
+  const void* src = P.src[k];
+  const long ld = P.ld[k];
+  const bool bf = P.bf16[k] != 0;
+  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + col;
+  const int r1 = min(rows, (int)(blockIdx.y + 1) * XA_COLSUM_ROWS);
+  float s0 = 0.f;
+  if (o < cols)
+    for (int r = blockIdx.y * XA_COLSUM_ROWS + rg; r < r1; r += 4)
+      s0 += bf ? load1<true>(src, (size_t)((long)r * ld + o)) : load1<false>(src, (size_t)((long)r * ld + o));
+  red[rg][col] = s0;
+  __syncthreads();
+  if (rg == 0 && o < cols) atomicAdd(&P.dst[k][o], (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]));
+}
+
 inline int pad_heads(int H) {
   int p = 1;
   while (p < H) p <<= 1;
@@ -339,5 +601,127 @@ extern "C" int vqaf_token_outer(const float* ca, const float* va, const float* c
       default: hipLaunchKernelGGL((token_outer_kernel<false, 8>), grid, block, smem, st, ca, va, cb, vb, N, D, H, out); break;
     }
   }
+  VQAF_LAUNCH_CHECK();
+}
+
+#define XA_BY_DT_HP(KERNEL, ...)                                                                      \
+  do {                                                                                                \
+    if (dtype == VQAF_BF16) {                                                                         \
+      switch (HP) {                                                                                   \
+        case 1: XA_LAUNCH_ONE((KERNEL<true, 1 XA_EXTRA>), __VA_ARGS__); break;                        \
+        case 2: XA_LAUNCH_ONE((KERNEL<true, 2 XA_EXTRA>), __VA_ARGS__); break;                        \
+        case 4: XA_LAUNCH_ONE((KERNEL<true, 4 XA_EXTRA>), __VA_ARGS__); break;                        \
+        default: XA_LAUNCH_ONE((KERNEL<true, 8 XA_EXTRA>), __VA_ARGS__); break;                       \
+      }                                                                                               \
+    } else {                                                                                          \
+      switch (HP) {                                                                                   \
+        case 1: XA_LAUNCH_ONE((KERNEL<false, 1 XA_EXTRA>), __VA_ARGS__); break;                       \
+        case 2: XA_LAUNCH_ONE((KERNEL<false, 2 XA_EXTRA>), __VA_ARGS__); break;                       \
+        case 4: XA_LAUNCH_ONE((KERNEL<false, 4 XA_EXTRA>), __VA_ARGS__); break;                       \
+        default: XA_LAUNCH_ONE((KERNEL<false, 8 XA_EXTRA>), __VA_ARGS__); break;                      \
+      }                                                                                               \
+    }                                                                                                 \
+  } while (0)
+// (a kernel whose LDS request exceeds 64 KiB needs the attribute; setting it every time is a host-side no-op)
+#define XA_LAUNCH_ONE(K, grid, block, smem, st, ...)                                                  \
+  do {                                                                                                \
+    if (smem > 48 * 1024 &&                                                                           \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)smem) != hipSuccess)                                                 \
+      return VQAF_E_LAUNCH;                                                                           \
+    hipLaunchKernelGGL(K, grid, block, smem, st, __VA_ARGS__);                                        \
+  } while (0)
+
+constexpr size_t XA_MAX_LDS = 128 * 1024;
+
+extern "C" int vqaf_softmax_wsum_multi(const vqaf_dense_fwd_mod* mods_host, int n, int B, int D, int H, int dtype,
+                                       vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(mods_host != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(n > 0 && n <= XA_MAX_MODS && B > 0 && B <= 65535 && D > 0 && H > 0 && H <= 8, VQAF_E_SHAPE);
+  VQAF_REQUIRE(D % 8 == 0, VQAF_E_ALIGN);
+  const int HP = pad_heads(H);
+  XaFwdMods mods = {};
+  int n_max = 0;
+  for (int i = 0; i < n; ++i) {
+    const vqaf_dense_fwd_mod& h = mods_host[i];
+    VQAF_REQUIRE(h.seq && h.s && h.p && h.z, VQAF_E_NULL);
+    VQAF_REQUIRE(h.N > 0, VQAF_E_SHAPE);
+    VQAF_REQUIRE(vqaf_aligned16(h.seq), VQAF_E_ALIGN);
+    mods.m[i] = XaFwdMod{h.seq, h.s, h.p, h.z, h.N};
+    n_max = h.N > n_max ? h.N : n_max;
+  }
+  const size_t smem = ((size_t)HP * n_max + (size_t)XA_THREADS * 8 + 2 * HP) * sizeof(float);
+  VQAF_REQUIRE(smem <= XA_MAX_LDS, VQAF_E_SHAPE);
+  const dim3 grid((D + XA_SLW - 1) / XA_SLW, B, n), block(XA_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+#define XA_EXTRA
+  XA_BY_DT_HP(softmax_wsum_multi_kernel, grid, block, smem, st, mods, D, H);
+#undef XA_EXTRA
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_token_bwd_multi(const vqaf_dense_bwd_mod* mods_host, int n, int B, int D, int H, int dtype,
+                                    vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(mods_host != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
+  VQAF_REQUIRE(n > 0 && n <= XA_MAX_MODS && B > 0 && B <= 65535 && D > 0 && H > 0 && H <= 8, VQAF_E_SHAPE);
+  VQAF_REQUIRE(D % 8 == 0, VQAF_E_ALIGN);
+  const int HP = pad_heads(H);
+  XaBwdMods mods = {};
+  int n_max = 0;
+  const bool need_u = mods_host[0].du != nullptr, need_seq = mods_host[0].grad_seq != nullptr;
+  VQAF_REQUIRE(need_u || need_seq, VQAF_E_NULL);
+  for (int i = 0; i < n; ++i) {
+    const vqaf_dense_bwd_mod& h = mods_host[i];
+    VQAF_REQUIRE(h.seq && h.p && h.dp && h.u && h.t, VQAF_E_NULL);
+    // one instantiation serves the launch: every problem asks for the same outputs
+    VQAF_REQUIRE((h.du != nullptr) == need_u && (h.grad_seq != nullptr) == need_seq, VQAF_E_NULL);
+    VQAF_REQUIRE(h.N > 0, VQAF_E_SHAPE);
+    VQAF_REQUIRE(vqaf_aligned16(h.seq) && vqaf_aligned16(h.u) && vqaf_aligned16(h.t) &&
+                     (h.grad_seq == nullptr || vqaf_aligned16(h.grad_seq)), VQAF_E_ALIGN);
+    mods.m[i] = XaBwdMod{h.seq, h.p, h.dp, h.u, h.t, h.du, h.grad_seq, h.N};
+    n_max = h.N > n_max ? h.N : n_max;
+  }
+  const size_t smem = ((size_t)2 * HP * n_max + (size_t)XA_THREADS * 8 + HP) * sizeof(float);
+  VQAF_REQUIRE(smem <= XA_MAX_LDS, VQAF_E_SHAPE);
+  const dim3 grid((D + XA_SLW - 1) / XA_SLW, B, n), block(XA_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  if (need_u && need_seq) {
+#define XA_EXTRA , true, true
+    XA_BY_DT_HP(token_bwd_multi_kernel, grid, block, smem, st, mods, D, H);
+#undef XA_EXTRA
+  } else if (need_seq) {
+#define XA_EXTRA , false, true
+    XA_BY_DT_HP(token_bwd_multi_kernel, grid, block, smem, st, mods, D, H);
+#undef XA_EXTRA
+  } else {
+#define XA_EXTRA , true, false
+    XA_BY_DT_HP(token_bwd_multi_kernel, grid, block, smem, st, mods, D, H);
+#undef XA_EXTRA
+  }
+  VQAF_LAUNCH_CHECK();
+}
+
+extern "C" int vqaf_colsum_multi(int n, const void* const* src_host, const int* src_dtype_host, const long* ld_host,
+                                 float* const* dst_host, int rows, int cols, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(src_host && src_dtype_host && ld_host && dst_host, VQAF_E_NULL);
+  VQAF_REQUIRE(n > 0 && n <= XA_MAX_COLSUMS && rows > 0 && cols > 0, VQAF_E_SHAPE);
+  XaColsums P = {};
+  for (int i = 0; i < n; ++i) {
+    VQAF_REQUIRE(src_host[i] && dst_host[i], VQAF_E_NULL);
+    VQAF_REQUIRE(vqaf_dtype_ok(src_dtype_host[i]), VQAF_E_DTYPE);
+    VQAF_REQUIRE(ld_host[i] >= cols, VQAF_E_SHAPE);
+    P.src[i] = src_host[i];
+    P.dst[i] = dst_host[i];
+    P.ld[i] = ld_host[i];
+    P.bf16[i] = src_dtype_host[i] == VQAF_BF16;
+  }
+  const dim3 grid((cols + 63) / 64, (rows + XA_COLSUM_ROWS - 1) / XA_COLSUM_ROWS, n);
+  VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);
+  hipLaunchKernelGGL(colsum_multi_kernel, grid, dim3(XA_THREADS), 0, (hipStream_t)stream, P, rows, cols);
   VQAF_LAUNCH_CHECK();
 }

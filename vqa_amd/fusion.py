@@ -261,7 +261,8 @@ class CoAttention(nn.Module):
         self.fuse_pool = True
         self.fuse_select = True  # scoring + selection + pooling of a sample in one workgroup (bf16 tokens)
         self.score_order = "fold"  # "reference": rank tokens with the reference's own operation order
-        self.overlap_branches = True  # dense (non-pruning) mode: the two attention branches on two streams
+        self.batch_branches = True  # dense (non-pruning) mode: the two attention branches share every launch
+        self.overlap_branches = True  # ... or, where that form does not apply, run on two streams
         if use_pruning:
             self.v_pruning = PrivacyAwareTokenPruning(
                 prune_ratio=prune_ratio, mixup_alpha=mixup_alpha, adversarial_mix=adversarial_mix,
@@ -349,7 +350,11 @@ class CoAttention(nn.Module):
             attended_v = ops.mean_pool(v_pruned)
             attended_q = ops.mean_pool(q_pruned)
         else:
-            from .xattn import single_query_attention
+            from .xattn import dense_coattention, dense_coattention_supported, single_query_attention
+            mhas, queries, seqs = (self.txt_to_vis_attn, self.vis_to_txt_attn), (q_global, v_global), (v_seq, q_seq)
+            if self.batch_branches and dense_coattention_supported(mhas, queries, seqs):
+                # both branches in the same launches (:257-261 and :264-268), concatenated by the last one (:274)
+                return dense_coattention(mhas, queries, seqs)
             side = _side_stream(v_seq.device) if self.overlap_branches else None
             if side is not None:
                 # The two branches are independent chains of small launches (a dozen forward, two dozen

@@ -82,16 +82,18 @@ class _SingleQueryTokens(torch.autograd.Function):
                                 ctx.needs_input_grad[1])
 
 
-def _zeroed(dev, *shapes):
+def _zeroed(dev, *shapes, with_flat=False):
     """f32 tensors of the given shapes carved out of ONE zero-filled allocation (one fill launch): outputs of
-    _gemm(..., into_zeros=True), which then adds into them instead of clearing each one with its own memset."""
+    _gemm(..., into_zeros=True), which then adds into them instead of clearing each one with its own memset.
+    with_flat: also returns the allocation itself and the pieces' element offsets in it."""
     sizes = [(math.prod(sh) + 3) // 4 * 4 for sh in shapes]  # 16-byte aligned pieces
     flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-    out, o = [], 0
+    out, offs, o = [], [], 0
     for sh, n in zip(shapes, sizes):
         out.append(flat[o:o + math.prod(sh)].view(sh))
+        offs.append(o)
         o += n
-    return out
+    return (out, flat, offs) if with_flat else out
 
 
 def _gemm(A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha=1.0, bias=None, bias_sg=0, into_zeros=False):
@@ -211,6 +213,209 @@ class _DenseSingleQuery(torch.autograd.Function):
         cast = lambda x, d: None if x is None else (x if x.dtype == d else x.to(d))  # noqa: E731
         return (cast(d_q.view(ctx.q_shape), qd) if d_q is not None else None, gseq, cast(d_win, wid),
                 cast(d_bin, bid), cast(d_wout, wod), cast(d_bout, bod), None)
+
+
+def _gemm_sets(A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha=1.0, bias=None, bias_sg=0):
+    """_gemm for several problems of ONE shape, stride set and dtype set in one launch: A, Bm, C (and bias)
+    are lists of (tensor, element offset) pairs, one per problem.  The outputs are ADDED into C, which the
+    caller provides zero-filled (long contractions are split over workgroups with f32 atomics)."""
+    import ctypes
+
+    def addrs(pairs):
+        return (ctypes.c_void_p * len(pairs))(*[t.data_ptr() + off * t.element_size() for t, off in pairs])
+
+    def code(t):
+        return _lib.BF16 if t.dtype == torch.bfloat16 else _lib.F32
+
+    n = len(A)
+    at, bt, ct = A[0][0], Bm[0][0], C[0][0]
+    assert ct.dtype == torch.float32 and all(a.dtype == at.dtype for a, _ in A) and all(b.dtype == bt.dtype for b, _ in Bm)
+    assert at.dtype in (torch.float32, torch.bfloat16) and bt.dtype in (torch.float32, torch.bfloat16)
+    check(load().vqaf_gemm_f32_atomic_sets(
+        n, addrs(A), code(at), a_s[0], a_s[1], a_s[2], addrs(Bm), code(bt), b_s[0], b_s[1], b_s[2],
+        addrs(bias) if bias is not None else None, code(bias[0][0]) if bias is not None else _lib.F32, bias_sg,
+        addrs(C), c_s[0], c_s[1], G, M, N, K, float(alpha), 1, stream_ptr(ct.device)), "vqaf_gemm_f32_atomic_sets")
+
+
+class _DenseCoAttention(torch.autograd.Function):
+    """The attention outputs of SEVERAL single-query MHA calls of one batch size and width -- the two branches
+    of CoAttention without pruning (utils/fusion.py:257-268) -- concatenated along the feature axis, with every
+    step of every branch in the same launch as its counterpart: one query fold, one scoring launch, one
+    softmax + weighted-token-sum launch, one launch per (B,E)-sized projection; the backward likewise (the
+    softmax backward, the folded-query gradient and the token gradient share one pass over the tokens).
+    Same arithmetic as _DenseSingleQuery per branch."""
+
+    @staticmethod
+    def forward(ctx, H, out_dtype, *flat):
+        import ctypes
+        nb = len(flat) // 6
+        br = [flat[6 * i:6 * i + 6] for i in range(nb)]
+        B, _, E = br[0][1].shape
+        dh = E // H
+        dev = br[0][1].device
+        lib, st = load(), stream_ptr(dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        q_c = [b[0].reshape(B, E).contiguous() for b in br]
+        if any(q.dtype not in (torch.float32, torch.bfloat16) or q.dtype != q_c[0].dtype for q in q_c):
+            q_c = [q.float() for q in q_c]
+        seq_c = [b[1].contiguous() for b in br]
+        w_in = [b[2].detach().contiguous() for b in br]
+        b_in = [b[3].detach().to(w.dtype).contiguous() for b, w in zip(br, w_in)]
+        w_out = [b[4].detach().contiguous() for b in br]
+        b_out = [b[5].detach().to(w.dtype).contiguous() for b, w in zip(br, w_out)]
+        Ns = [s.shape[1] for s in seq_c]
+        qp, u, z = torch.empty(nb, B, E, **f32), torch.empty(nb, B, H, E, **f32), torch.empty(nb, B, H, E, **f32)
+        folds = (_lib.FoldDesc * nb)(*[_lib.FoldDesc(ptr(q_c[i]), ptr(w_in[i]), ptr(b_in[i]), ptr(qp[i]), ptr(u[i]))
+                                       for i in range(nb)])
+        check(lib.vqaf_fold_query_multi(ctypes.cast(folds, ctypes.c_void_p), nb, B, E, H, dtype_code(q_c[0]),
+                                        dtype_code(w_in[0]), st), "vqaf_fold_query_multi")
+        s = [torch.empty(B, n, H, **f32) for n in Ns]
+        sd = (_lib.ScoresDesc * nb)(*[_lib.ScoresDesc(ptr(seq_c[i]), ptr(u[i]), ptr(s[i]), Ns[i]) for i in range(nb)])
+        check(lib.vqaf_head_scores_multi(ctypes.cast(sd, ctypes.c_void_p), nb, B, E, H, dtype_code(seq_c[0]), st),
+              "vqaf_head_scores_multi")
+        p = [torch.empty(B, H, n, **f32) for n in Ns]
+        fm = (_lib.DenseFwdMod * nb)(*[_lib.DenseFwdMod(ptr(seq_c[i]), ptr(s[i]), ptr(p[i]), ptr(z[i]), Ns[i])
+                                       for i in range(nb)])
+        check(lib.vqaf_softmax_wsum_multi(ctypes.cast(fm, ctypes.c_void_p), nb, B, E, H, dtype_code(seq_c[0]), st),
+              "vqaf_softmax_wsum_multi")
+        attn, out = _zeroed(dev, (nb, B, E), (B, nb * E))
+        # attn_i[:, head h] = z_i[:,h,:] Wv_i[head h, :]^T + bv_i[head h]
+        _gemm_sets([(z[i], 0) for i in range(nb)], (E, H * E, 1), [(w_in[i], 2 * E * E) for i in range(nb)],
+                   (dh * E, 1, E), [(attn[i], 0) for i in range(nb)], (dh, E), H, B, dh, E,
+                   bias=[(b_in[i], 2 * E) for i in range(nb)], bias_sg=dh)
+        # out[:, i*E:(i+1)*E] = attn_i Wout_i^T + bout_i
+        _gemm_sets([(attn[i], 0) for i in range(nb)], (0, E, 1), [(w_out[i], 0) for i in range(nb)], (0, 1, E),
+                   [(out, i * E) for i in range(nb)], (0, nb * E), 1, B, E, E, bias=[(b_out[i], 0) for i in range(nb)])
+        ctx.save_for_backward(qp, u, z, attn, *q_c, *seq_c, *w_in, *w_out, *p)
+        ctx.H, ctx.nb = H, nb
+        ctx.dtypes = [tuple(t.dtype for t in (b[0], b[2], b[3], b[4], b[5])) for b in br]
+        ctx.q_shapes = [b[0].shape for b in br]
+        return out if out.dtype == out_dtype else out.to(out_dtype)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        import ctypes
+        nb, H = ctx.nb, ctx.H
+        saved = ctx.saved_tensors
+        qp, u, z, attn = saved[:4]
+        q_c, seq_c, w_in, w_out, p = (saved[4 + k * nb:4 + (k + 1) * nb] for k in range(5))
+        B, _, E = seq_c[0].shape
+        dh = E // H
+        dev = seq_c[0].device
+        lib, st = load(), stream_ptr(dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        Ns = [s.shape[1] for s in seq_c]
+        need = [ctx.needs_input_grad[2 + 6 * i:8 + 6 * i] for i in range(nb)]  # (q, seq, w_in, b_in, w_out, b_out)
+        need_q = any(n[0] for n in need)
+        need_seq = any(n[1] for n in need)
+        need_par = any(any(n[2:]) for n in need)
+        need_u = need_q or need_par
+        g = g_out.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        scale = 1.0 / math.sqrt(dh)
+        rng = range(nb)
+        # internal products first, then everything that is handed back (one block, so that one cast serves it)
+        shapes = ((nb, B, E), (nb, B, H, E), (nb, B, E), (nb, B, E), (nb, 3 * E, E), (nb, 3 * E), (nb, E, E), (nb, E))
+        (d_attn, t, d_qp, d_q, d_win, d_bin, d_wout, d_bout), zflat, zoffs = _zeroed(dev, *shapes, with_flat=True)
+        # through the output projection: d_attn_i = g[:, i*E:(i+1)*E] Wout_i
+        _gemm_sets([(g, i * E) for i in rng], (0, nb * E, 1), [(w_out[i], 0) for i in rng], (0, E, 1),
+                   [(d_attn[i], 0) for i in rng], (0, E), 1, B, E, E)
+        # through the value projection: t_i[:,h,:] = d_attn_i[:, head h] Wv_i[head h, :]
+        _gemm_sets([(d_attn[i], 0) for i in rng], (dh, E, 1), [(w_in[i], 2 * E * E) for i in rng], (dh * E, E, 1),
+                   [(t[i], 0) for i in rng], (E, H * E), H, B, E, dh)
+        # through the token passes
+        dp = [torch.empty(B, n, H, **f32) for n in Ns]
+        sd = (_lib.ScoresDesc * nb)(*[_lib.ScoresDesc(ptr(seq_c[i]), ptr(t[i]), ptr(dp[i]), Ns[i]) for i in rng])
+        check(lib.vqaf_head_scores_multi(ctypes.cast(sd, ctypes.c_void_p), nb, B, E, H, dtype_code(seq_c[0]), st),
+              "vqaf_head_scores_multi")
+        du = torch.empty(nb, B, H, E, **f32) if need_u else None
+        gseq = [torch.empty_like(s) for s in seq_c] if need_seq else [None] * nb
+        if need_u or need_seq:
+            bm = (_lib.DenseBwdMod * nb)(*[_lib.DenseBwdMod(ptr(seq_c[i]), ptr(p[i]), ptr(dp[i]), ptr(u[i]), ptr(t[i]),
+                                                          ptr(du[i]) if need_u else None, ptr(gseq[i]), Ns[i])
+                                           for i in rng])
+            check(lib.vqaf_token_bwd_multi(ctypes.cast(bm, ctypes.c_void_p), nb, B, E, H, dtype_code(seq_c[0]), st),
+                  "vqaf_token_bwd_multi")
+        if need_u:
+            # d_qp_i[:, head h] = du_i[:,h,:] Wk_i[head h, :]^T / sqrt(dh)
+            _gemm_sets([(du[i], 0) for i in rng], (E, H * E, 1), [(w_in[i], E * E) for i in rng], (dh * E, 1, E),
+                       [(d_qp[i], 0) for i in rng], (dh, E), H, B, dh, E, alpha=scale)
+        if need_q:
+            _gemm_sets([(d_qp[i], 0) for i in rng], (0, E, 1), [(w_in[i], 0) for i in rng], (0, E, 1),
+                       [(d_q[i], 0) for i in rng], (0, E), 1, B, E, E)
+        if need_par:
+            # dWout_i = g_i^T attn_i;  dWv_i[head h rows] = d_attn_i[:, head h]^T z_i[:,h,:]
+            _gemm_sets([(g, i * E) for i in rng], (0, 1, nb * E), [(attn[i], 0) for i in rng], (0, E, 1),
+                       [(d_wout[i], 0) for i in rng], (0, E), 1, E, E, B)
+            _gemm_sets([(d_attn[i], 0) for i in rng], (dh, 1, E), [(z[i], 0) for i in rng], (E, H * E, 1),
+                       [(d_win[i], 2 * E * E) for i in rng], (dh * E, E), H, dh, E, B)
+            # dWk_i[head h rows] = qp_i[:, head h]^T du_i[:,h,:] / sqrt(dh);  dWq_i = d_qp_i^T query_i
+            _gemm_sets([(qp[i], 0) for i in rng], (dh, 1, E), [(du[i], 0) for i in rng], (E, H * E, 1),
+                       [(d_win[i], E * E) for i in rng], (dh * E, E), H, dh, E, B, alpha=scale)
+            _gemm_sets([(d_qp[i], 0) for i in rng], (0, 1, E), [(q_c[i], 0) for i in rng], (0, E, 1),
+                       [(d_win[i], 0) for i in rng], (0, E), 1, E, E, B)
+            # bias gradients: column sums of g, d_attn (value bias) and d_qp (query bias); the key bias shifts every
+            # score of a head alike and keeps its exact zero
+            srcs = [(g, i * E, nb * E) for i in rng] + [(d_attn[i], 0, E) for i in rng] + [(d_qp[i], 0, E) for i in rng]
+            dsts = [(d_bout[i], 0) for i in rng] + [(d_bin[i], 2 * E) for i in rng] + [(d_bin[i], 0) for i in rng]
+            k = len(srcs)
+            check(lib.vqaf_colsum_multi(
+                k, (ctypes.c_void_p * k)(*[t_.data_ptr() + o * t_.element_size() for t_, o, _ in srcs]),
+                (ctypes.c_int * k)(*[dtype_code(t_) for t_, _, _ in srcs]), (ctypes.c_long * k)(*[ld for _, _, ld in srcs]),
+                (ctypes.c_void_p * k)(*[t_.data_ptr() + o * 4 for t_, o in dsts]), B, E, st), "vqaf_colsum_multi")
+        # hand back in the inputs' dtypes: when they all share one (the usual bf16 module), ONE cast of the block
+        # of returned products serves every gradient
+        want = {d for dts, n in zip(ctx.dtypes, need) for d, nd in zip(dts, (n[0], n[2], n[3], n[4], n[5])) if nd}
+        if len(want) == 1 and next(iter(want)) != torch.float32:
+            lo = zoffs[3]
+            block = zflat[lo:].to(next(iter(want)))
+            d_q, d_win, d_bin, d_wout, d_bout = (block[o - lo:o - lo + math.prod(sh)].view(sh)
+                                                 for o, sh in zip(zoffs[3:], shapes[3:]))
+        grads = [None, None]
+        for i in rng:
+            qd, wid, bid, wod, bod = ctx.dtypes[i]
+            n = need[i]
+            cast = lambda x, d: x if x.dtype == d else x.to(d)  # noqa: E731
+            grads += [cast(d_q[i].view(ctx.q_shapes[i]), qd) if n[0] else None,
+                      gseq[i] if n[1] else None,
+                      cast(d_win[i], wid) if n[2] else None,
+                      cast(d_bin[i], bid) if n[3] else None,
+                      cast(d_wout[i], wod) if n[4] else None,
+                      cast(d_bout[i], bod) if n[5] else None]
+        return tuple(grads)
+
+
+def dense_coattention_supported(mhas, queries, seqs) -> bool:
+    """True when dense_coattention() covers these branches: one batch size, width, head count and set of
+    dtypes, at most four branches, at most 8 heads, per-sample coefficients within the kernels' LDS."""
+    if not (1 <= len(mhas) <= 4) or any(s.dim() != 3 for s in seqs):
+        return False
+    B, _, E = seqs[0].shape
+    H = mhas[0].num_heads
+    if H > 8 or E % H != 0 or E % 8 != 0 or B > 65535:
+        return False
+    for m, q, s in zip(mhas, queries, seqs):
+        if s.shape[0] != B or s.shape[2] != E or m.num_heads != H or q.numel() != B * E or \
+                s.dtype != seqs[0].dtype or s.dtype not in (torch.float32, torch.bfloat16) or \
+                q.dtype != queries[0].dtype or m.in_proj_weight is None or \
+                m.in_proj_weight.dtype != mhas[0].in_proj_weight.dtype or \
+                m.out_proj.weight.dtype != mhas[0].out_proj.weight.dtype or \
+                m.in_proj_weight.dtype not in (torch.float32, torch.bfloat16) or m.in_proj_bias is None or \
+                m.out_proj.bias is None:
+            return False
+        if (2 * 8 * s.shape[1] + 2048 + 8) * 4 > 128 * 1024:
+            return False
+    return True
+
+
+def dense_coattention(mhas, queries, seqs) -> torch.Tensor:
+    """cat_i MHA_i(query_i[:,None], seq_i, seq_i) along the feature axis, (B, len(mhas) * E) in the tokens'
+    dtype, every branch in the same launches (see _DenseCoAttention)."""
+    flat = []
+    for m, q, s in zip(mhas, queries, seqs):
+        flat += [q, s, m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias]
+    return _DenseCoAttention.apply(mhas[0].num_heads, seqs[0].dtype, *flat)
 
 
 def single_query_attention(mha: nn.MultiheadAttention, query: torch.Tensor, seq: torch.Tensor) -> torch.Tensor:
