@@ -287,7 +287,7 @@ def dense_leg(dev, dtype):
     out = {}
     for B, N in ((64, 197), (128, 577)):
         torch.manual_seed(1)
-        m = fusion.CoAttention(embed_dim=D, num_heads=8, use_pruning=False).to(dev)
+        m = fusion.CoAttention(embed_dim=D, num_heads=8, use_pruning=False).to(dev).to(dtype)  # as the step's fusion module
         gen = torch.Generator(device=dev).manual_seed(3)
         v = torch.randn(B, N, D, device=dev, generator=gen).to(dtype).requires_grad_()
         q = torch.randn(B, N_TXT, D, device=dev, generator=gen).to(dtype).requires_grad_()

@@ -12,7 +12,7 @@ dtype = torch.float32 if len(sys.argv) > 3 and sys.argv[3] == "f32" else torch.b
 dev = torch.device("cuda:0")
 D, NQ = 512, 30
 torch.manual_seed(1)
-m = fusion.CoAttention(embed_dim=D, num_heads=8, use_pruning=False).to(dev)
+m = fusion.CoAttention(embed_dim=D, num_heads=8, use_pruning=False).to(dev).to(dtype)  # as the step's fusion module
 gen = torch.Generator(device=dev).manual_seed(3)
 v = torch.randn(B, N, D, device=dev, generator=gen).to(dtype).requires_grad_()
 q = torch.randn(B, NQ, D, device=dev, generator=gen).to(dtype).requires_grad_()

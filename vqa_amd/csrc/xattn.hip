@@ -289,48 +289,101 @@ __device__ __forceinline__ void xa_block_reduce(float (&v)[HP], float (*red)[HP]
   __syncthreads();
 }
 
+typedef float xa_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ xa_f32x2 xa_fma2(float w, xa_f32x2 x, xa_f32x2 a) {
+  // two FMAs in one packed instruction (v_pk_fma_f32): each element is the same correctly rounded fmaf
+  return __builtin_elementwise_fma(xa_f32x2{w, w}, x, a);
+}
+// A token row piece (8 columns) as it arrives from memory: bf16 rows stay packed until they are multiplied.
+template <bool BF16>
+struct XaRaw {
+  u32x4 r[BF16 ? 1 : 2];
+};
+template <bool BF16>
+__device__ __forceinline__ XaRaw<BF16> xa_load_raw(const void* __restrict__ seq, size_t e) {
+  XaRaw<BF16> x;
+  if constexpr (BF16) {
+    x.r[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(seq) + e);
+  } else {
+    x.r[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(seq) + e);
+    x.r[1] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(seq) + e + 4);
+  }
+  return x;
+}
+template <bool BF16>
+__device__ __forceinline__ void xa_unpack(const XaRaw<BF16>& x, xa_f32x2 (&v)[4]) {
+  if constexpr (BF16) {
+    const u32x4 r = x.r[0];
+    v[0] = xa_f32x2{bf16_lo(r.x), bf16_hi(r.x)}; v[1] = xa_f32x2{bf16_lo(r.y), bf16_hi(r.y)};
+    v[2] = xa_f32x2{bf16_lo(r.z), bf16_hi(r.z)}; v[3] = xa_f32x2{bf16_lo(r.w), bf16_hi(r.w)};
+  } else {
+    const u32x4 a = x.r[0], c = x.r[1];
+    v[0] = xa_f32x2{__uint_as_float(a.x), __uint_as_float(a.y)}; v[1] = xa_f32x2{__uint_as_float(a.z), __uint_as_float(a.w)};
+    v[2] = xa_f32x2{__uint_as_float(c.x), __uint_as_float(c.y)}; v[3] = xa_f32x2{__uint_as_float(c.z), __uint_as_float(c.w)};
+  }
+}
+
 // The weighted-sum pass of weighted_token_sum_kernel over coefficients already token-major in LDS
-// (cs[n * CP + h], h < HP) and its fixed-order fold into z[b,h,slice].
+// (cs[n * CP + h], h < HP) and its fixed-order fold into z[b,h,slice].  Rows are requested one batch ahead of
+// the batch being multiplied (`first` holds the first batch, requested by the caller before its own prologue).
+constexpr int XA_WS_U = 2;  // rows per lane and batch
+template <bool BF16>
+__device__ __forceinline__ void xa_ws_fetch(const void* __restrict__ seq, int b, int N, int D, int n0,
+                                            XaRaw<BF16> (&dst)[XA_WS_U]) {
+  const int li = threadIdx.x % XA_LPR;
+  const int d0 = min((int)blockIdx.x * XA_SLW + li * 8, D - 8);  // (a slice past the width is never accumulated)
+#pragma unroll
+  for (int u = 0; u < XA_WS_U; ++u)  // rows past the end re-read the last one; their weight is zeroed
+    dst[u] = xa_load_raw<BF16>(seq, ((size_t)b * N + min(n0 + u * XA_ROWS, N - 1)) * D + d0);
+}
 template <bool BF16, int HP, int CP>
 __device__ __forceinline__ void xa_weighted_sum(const void* __restrict__ seq, const float* cs, float* red, int b,
-                                                int N, int D, int H, float* __restrict__ z) {
-  constexpr int U = 4;
+                                                int N, int D, int H, float* __restrict__ z,
+                                                XaRaw<BF16> (&cur)[XA_WS_U]) {
+  constexpr int U = XA_WS_U;
   const int tid = threadIdx.x, g = tid / XA_LPR, li = tid % XA_LPR;
   const int d0 = blockIdx.x * XA_SLW + li * 8;
-  float acc[HP][8];
+  xa_f32x2 acc[HP][4];
 #pragma unroll
   for (int h = 0; h < HP; ++h)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[h][i] = 0.f;
-  if (d0 < D) {
-    for (int n0 = g; n0 < N; n0 += U * XA_ROWS) {
-      float x[U][8];
+    for (int i = 0; i < 4; ++i) acc[h][i] = xa_f32x2{0.f, 0.f};
+  auto multiply = [&](const XaRaw<BF16> (&rows)[U], int n0) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        load8<BF16>(seq, ((size_t)b * N + min(n0 + u * XA_ROWS, N - 1)) * D + d0, x[u]);
+    for (int u = 0; u < U; ++u) {
+      xa_f32x2 x[4];
+      xa_unpack<BF16>(rows[u], x);
+      const int n = n0 + u * XA_ROWS;
+      const bool in = n < N;
+      const float* cw = cs + (size_t)min(n, N - 1) * CP;
+      float w[HP];
+      if constexpr (HP >= 4) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int n = n0 + u * XA_ROWS;
-        const bool in = n < N;
-        const float* cw = cs + (size_t)min(n, N - 1) * CP;
-        float w[HP];
-        if constexpr (HP >= 4) {
-#pragma unroll
-          for (int h = 0; h < HP; h += 4) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(cw + h);
-            w[h] = q.x; w[h + 1] = q.y; w[h + 2] = q.z; w[h + 3] = q.w;
-          }
-        } else {
-#pragma unroll
-          for (int h = 0; h < HP; ++h) w[h] = cw[h];
+        for (int h = 0; h < HP; h += 4) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(cw + h);
+          w[h] = q.x; w[h + 1] = q.y; w[h + 2] = q.z; w[h + 3] = q.w;
         }
+      } else {
 #pragma unroll
-        for (int h = 0; h < HP; ++h) {
-          const float wh = in ? w[h] : 0.f;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) acc[h][i] = fmaf(wh, x[u][i], acc[h][i]);
-        }
+        for (int h = 0; h < HP; ++h) w[h] = cw[h];
       }
+#pragma unroll
+      for (int h = 0; h < HP; ++h) {
+        const float wh = in ? w[h] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[h][i] = xa_fma2(wh, x[i], acc[h][i]);
+      }
+    }
+  };
+  if (d0 < D) {
+    // two register sets take turns (no copies: a copy of a register that a load is still writing would wait
+    // for the load): while one batch is multiplied the next one is on its way
+    XaRaw<BF16> other[U];
+    for (int n0 = g; n0 < N; n0 += 2 * U * XA_ROWS) {
+      xa_ws_fetch<BF16>(seq, b, N, D, n0 + U * XA_ROWS, other);
+      multiply(cur, n0);
+      xa_ws_fetch<BF16>(seq, b, N, D, n0 + 2 * U * XA_ROWS, cur);
+      multiply(other, n0 + U * XA_ROWS);  // rows past the end carry zero weight
     }
   }
   for (int h = 0; h < H; ++h) {
@@ -339,7 +392,7 @@ __device__ __forceinline__ void xa_weighted_sum(const void* __restrict__ seq, co
     for (int i = 0; i < 8; ++i) {
       float v = 0.f;
 #pragma unroll
-      for (int hh = 0; hh < HP; ++hh) v = (hh == h) ? acc[hh][i] : v;
+      for (int hh = 0; hh < HP; ++hh) v = (hh == h) ? acc[hh][i >> 1][i & 1] : v;
       red[tid * 8 + i] = v;
     }
     __syncthreads();
@@ -363,6 +416,8 @@ softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H) {
   float (*wred)[HP] = reinterpret_cast<float (*)[HP]>(red);  // the block reductions run before the sums use it
   float* stat = red + XA_THREADS * 8;               // [2][HP]
   const float* sb = M.s + (size_t)b * N * H;
+  XaRaw<BF16> first[XA_WS_U];  // the first rows travel while the softmax is computed
+  xa_ws_fetch<BF16>(M.seq, b, N, D, tid / XA_LPR, first);
   float m[HP], zz[HP];
 #pragma unroll
   for (int h = 0; h < HP; ++h) { m[h] = -INFINITY; zz[h] = 0.f; }
@@ -392,7 +447,7 @@ softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H) {
         if (blockIdx.x == 0) pb[(size_t)h * N + n] = pv;
       }
   __syncthreads();
-  xa_weighted_sum<BF16, HP, HP>(M.seq, cs, red, b, N, D, H, M.z);
+  xa_weighted_sum<BF16, HP, HP>(M.seq, cs, red, b, N, D, H, M.z, first);
 }
 
 template <bool BF16, int HP, bool NEED_U, bool NEED_SEQ>
@@ -407,6 +462,8 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
   float* stat = red + XA_THREADS * 8;               // [HP]
   const float* pb = M.p + (size_t)b * H * N;
   const float* dpb = M.dp + (size_t)b * N * H;
+  XaRaw<BF16> first[XA_WS_U];  // the first rows of the folded-query gradient's pass, requested up front
+  if constexpr (NEED_U) xa_ws_fetch<BF16>(M.seq, b, N, D, g, first);
   float acc[HP];
 #pragma unroll
   for (int h = 0; h < HP; ++h) acc[h] = 0.f;
@@ -428,15 +485,15 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
   if constexpr (NEED_SEQ) {
     const int d0 = blockIdx.x * XA_SLW + li * 8;
     if (d0 < D) {
-      float ra[HP][8], rb[HP][8];
+      xa_f32x2 ra[HP][4], rb[HP][4];
 #pragma unroll
       for (int h = 0; h < HP; ++h) {
         if (h < H) {
-          load8<false>(M.u, ((size_t)b * H + h) * D + d0, ra[h]);
-          load8<false>(M.t, ((size_t)b * H + h) * D + d0, rb[h]);
+          xa_unpack<false>(xa_load_raw<false>(M.u, ((size_t)b * H + h) * D + d0), ra[h]);
+          xa_unpack<false>(xa_load_raw<false>(M.t, ((size_t)b * H + h) * D + d0), rb[h]);
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) ra[h][i] = rb[h][i] = 0.f;
+          for (int i = 0; i < 4; ++i) ra[h][i] = rb[h][i] = xa_f32x2{0.f, 0.f};
         }
       }
       auto row = [&](int n, float (&o)[8]) {
@@ -451,12 +508,15 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
         } else {
           w[0] = cw[0]; w[1] = cw[1];
         }
+        xa_f32x2 o2[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+        for (int i = 0; i < 4; ++i) o2[i] = xa_f32x2{0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < HP; ++h)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = fmaf(w[h], ra[h][i], fmaf(w[HP + h], rb[h][i], o[i]));
+          for (int i = 0; i < 4; ++i) o2[i] = xa_fma2(w[h], ra[h][i], xa_fma2(w[HP + h], rb[h][i], o2[i]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[2 * i] = o2[i].x; o[2 * i + 1] = o2[i].y; }
       };
       int n = g;
       for (; n + XA_ROWS < N; n += 2 * XA_ROWS) {
@@ -473,7 +533,7 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
       }
     }
   }
-  if constexpr (NEED_U) xa_weighted_sum<BF16, HP, 2 * HP>(M.seq, cs, red, b, N, D, H, M.du);
+  if constexpr (NEED_U) xa_weighted_sum<BF16, HP, 2 * HP>(M.seq, cs, red, b, N, D, H, M.du, first);
 }
 
 // dst[c] += sum_r src[r * ld + c] for up to XA_MAX_COLSUMS (source, destination) pairs in one launch (f32 or

@@ -10,6 +10,7 @@ as the reference's module does.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 
 import torch
@@ -215,6 +216,21 @@ class _DenseSingleQuery(torch.autograd.Function):
                 cast(d_bin, bid), cast(d_wout, wod), cast(d_bout, bod), None)
 
 
+OVERLAP_WEIGHT_GRADS = True  # _DenseCoAttention.backward: weight gradients beside the token passes (second stream)
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device):
+    """A second stream of `device` (module level: an autograd function holds no state); None while a graph is
+    being captured before the stream exists (a stream cannot be created then)."""
+    st = _SIDE_STREAMS.get(device.index)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        st = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _gemm_sets(A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha=1.0, bias=None, bias_sg=0):
     """_gemm for several problems of ONE shape, stride set and dtype set in one launch: A, Bm, C (and bias)
     are lists of (tensor, element offset) pairs, one per problem.  The outputs are ADDED into C, which the
@@ -321,6 +337,22 @@ class _DenseCoAttention(torch.autograd.Function):
         # through the output projection: d_attn_i = g[:, i*E:(i+1)*E] Wout_i
         _gemm_sets([(g, i * E) for i in rng], (0, nb * E, 1), [(w_out[i], 0) for i in rng], (0, E, 1),
                    [(d_attn[i], 0) for i in rng], (0, E), 1, B, E, E)
+        # The products that depend only on d_attn and on tensors of the forward pass (two of the four weight
+        # gradients) run on a second stream beside the token passes: they are short launches that leave most of
+        # the chip idle, and the token kernels that follow on this stream do not need them.
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if (OVERLAP_WEIGHT_GRADS and need_par) else None
+        side_ctx = contextlib.nullcontext()
+        if side is not None:
+            side.wait_stream(main)
+            side_ctx = torch.cuda.stream(side)
+        if need_par:
+            with side_ctx:
+                # dWout_i = g_i^T attn_i;  dWv_i[head h rows] = d_attn_i[:, head h]^T z_i[:,h,:]
+                _gemm_sets([(g, i * E) for i in rng], (0, 1, nb * E), [(attn[i], 0) for i in rng], (0, E, 1),
+                           [(d_wout[i], 0) for i in rng], (0, E), 1, E, E, B)
+                _gemm_sets([(d_attn[i], 0) for i in rng], (dh, 1, E), [(z[i], 0) for i in rng], (E, H * E, 1),
+                           [(d_win[i], 2 * E * E) for i in rng], (dh * E, E), H, dh, E, B)
         # through the value projection: t_i[:,h,:] = d_attn_i[:, head h] Wv_i[head h, :]
         _gemm_sets([(d_attn[i], 0) for i in rng], (dh, E, 1), [(w_in[i], 2 * E * E) for i in rng], (dh * E, E, 1),
                    [(t[i], 0) for i in rng], (E, H * E), H, B, E, dh)
@@ -345,16 +377,13 @@ class _DenseCoAttention(torch.autograd.Function):
             _gemm_sets([(d_qp[i], 0) for i in rng], (0, E, 1), [(w_in[i], 0) for i in rng], (0, E, 1),
                        [(d_q[i], 0) for i in rng], (0, E), 1, B, E, E)
         if need_par:
-            # dWout_i = g_i^T attn_i;  dWv_i[head h rows] = d_attn_i[:, head h]^T z_i[:,h,:]
-            _gemm_sets([(g, i * E) for i in rng], (0, 1, nb * E), [(attn[i], 0) for i in rng], (0, E, 1),
-                       [(d_wout[i], 0) for i in rng], (0, E), 1, E, E, B)
-            _gemm_sets([(d_attn[i], 0) for i in rng], (dh, 1, E), [(z[i], 0) for i in rng], (E, H * E, 1),
-                       [(d_win[i], 2 * E * E) for i in rng], (dh * E, E), H, dh, E, B)
             # dWk_i[head h rows] = qp_i[:, head h]^T du_i[:,h,:] / sqrt(dh);  dWq_i = d_qp_i^T query_i
             _gemm_sets([(qp[i], 0) for i in rng], (dh, 1, E), [(du[i], 0) for i in rng], (E, H * E, 1),
                        [(d_win[i], E * E) for i in rng], (dh * E, E), H, dh, E, B, alpha=scale)
             _gemm_sets([(d_qp[i], 0) for i in rng], (0, 1, E), [(q_c[i], 0) for i in rng], (0, E, 1),
                        [(d_win[i], 0) for i in rng], (0, E), 1, E, E, B)
+            if side is not None:
+                main.wait_stream(side)
             # bias gradients: column sums of g, d_attn (value bias) and d_qp (query bias); the key bias shifts every
             # score of a head alike and keeps its exact zero
             srcs = [(g, i * E, nb * E) for i in rng] + [(d_attn[i], 0, E) for i in rng] + [(d_qp[i], 0, E) for i in rng]
