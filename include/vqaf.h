@@ -401,6 +401,25 @@ int vqaf_gemm_f32_atomic_sets(int n_sets, const void* const* A_host, int a_dtype
                               float* const* C_host, long c_sg, long c_sm, int G, int M, int N, int K,
                               float alpha, int beta_one, vqaf_stream_t stream);
 
+/* n <= 12 DIFFERENT strided-batched products (each as vqaf_gemm_f32_atomic describes it: own shape, strides,
+ * operand types) in ONE launch, each ADDED into its C, which the caller provides zero-filled (long
+ * contractions are split over workgroups with f32 atomics; the sum order is not fixed).  For groups of short
+ * products that do not depend on each other -- in the backward of the attention modules
+ * (utils/fusion.py:194-200, 257-268 under autograd) the input gradient through the value projection and two
+ * weight gradients all follow from one incoming gradient -- and would otherwise each occupy the stream for
+ * a launch of their own. */
+typedef struct vqaf_gemm_desc {
+  const void* A;    /* element (g, m, k) at A + g*a_sg + m*a_sm + k*a_sk (elements of a_dtype) */
+  const void* Bm;   /* element (g, k, n) at Bm + g*b_sg + k*b_sk + n*b_sn */
+  const void* bias; /* element (g, n) at bias + g*bias_sg + n, or NULL */
+  float* C;         /* element (g, m, n) at C + g*c_sg + m*c_sm + n */
+  long a_sg, a_sm, a_sk, b_sg, b_sk, b_sn, bias_sg, c_sg, c_sm;
+  int a_dtype, b_dtype, bias_dtype;
+  int G, M, N, K;
+  float alpha;
+} vqaf_gemm_desc;
+int vqaf_gemm_f32_group(int n, const vqaf_gemm_desc* probs_host, vqaf_stream_t stream);
+
 /* Both branches of the dense co-attention (utils/fusion.py:257-268) in the same launches, with the
  * per-sample softmax steps fused into the token passes; n <= 4 problems of one batch size, width and head
  * count, each with its own token count and buffers.  Results are bit-identical to the separate launches
@@ -410,6 +429,8 @@ int vqaf_gemm_f32_atomic_sets(int n_sets, const void* const* A_host, int a_dtype
  *                             z[b,h,:] = sum_n p[b,h,n] x_bn
  *   vqaf_token_bwd_multi:     ds = p * (dp - sum_n p dp) (kept on chip),  du[b,h,:] = sum_n ds[b,h,n] x_bn,
  *                             grad_seq[b,n,:] = sum_h ds[b,h,n] u[b,h,:] + p[b,h,n] t[b,h,:]
+ * vqaf_softmax_wsum_multi also clears zero_count f32 at zero_ptr on the side (may be 0 / NULL; nothing the launch
+ * reads or writes): the outputs that the projections behind it build with atomic adds.
  * du or grad_seq may be NULL (for every problem alike) when that gradient is not needed.  H <= 8,
  * D % 8 == 0, and the per-sample coefficients must fit 128 KiB of LDS (H*N*4, resp. 2*H*N*4 bytes + 8 KiB). */
 typedef struct vqaf_dense_fwd_mod {
@@ -420,7 +441,7 @@ typedef struct vqaf_dense_fwd_mod {
   int N;
 } vqaf_dense_fwd_mod;
 int vqaf_softmax_wsum_multi(const vqaf_dense_fwd_mod* mods_host, int n, int B, int D, int H, int dtype,
-                            vqaf_stream_t stream);
+                            float* zero_ptr, size_t zero_count, vqaf_stream_t stream);
 typedef struct vqaf_dense_bwd_mod {
   const void* seq; /* (B,N,D) `dtype` */
   const float* p;  /* (B,H,N) */
@@ -433,12 +454,6 @@ typedef struct vqaf_dense_bwd_mod {
 } vqaf_dense_bwd_mod;
 int vqaf_token_bwd_multi(const vqaf_dense_bwd_mod* mods_host, int n, int B, int D, int H, int dtype,
                          vqaf_stream_t stream);
-
-/* dst_i[c] += sum_r src_i[r * ld_i + c], c < cols, r < rows, for n <= 8 (source, destination) pairs in one
- * launch (sources f32 or bf16; destinations f32, zeroed by the caller; f32 atomics across row blocks): the
- * bias gradients of the attention modules' projections (utils/fusion.py:194-200 under autograd). */
-int vqaf_colsum_multi(int n, const void* const* src_host, const int* src_dtype_host, const long* ld_host,
-                      float* const* dst_host, int rows, int cols, vqaf_stream_t stream);
 
 /* bf16 GEMM on the matrix cores for the classifier's three uses of a Linear under DP-SGD
  * (model/model.py:54-63 wrapped at train.py:124-141):

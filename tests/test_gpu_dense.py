@@ -151,7 +151,7 @@ def test_batched_branches_equal_the_per_branch_launches(dev, B, Nv, Nq, dtype, n
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("H", [8, 4, 3])
 def test_fused_token_kernels_are_bit_identical_to_the_separate_launches(dev, dtype, H):
-    """vqaf_softmax_wsum_multi / vqaf_token_bwd_multi / vqaf_colsum_multi / vqaf_gemm_f32_atomic_sets through
+    """vqaf_softmax_wsum_multi / vqaf_token_bwd_multi / vqaf_gemm_f32_atomic_sets / vqaf_gemm_f32_group through
     the C ABI against the launches they replace, two problems of different token counts per launch."""
     import ctypes
     from vqa_amd import _lib
@@ -169,7 +169,10 @@ def test_fused_token_kernels_are_bit_identical_to_the_separate_launches(dev, dty
     p1 = [torch.empty(B, H, n, **f32) for n in Ns]
     z1 = [torch.empty(B, H, D, **f32) for _ in Ns]
     fm = (_lib.DenseFwdMod * 2)(*[_lib.DenseFwdMod(ptr(seqs[i]), ptr(ss[i]), ptr(p1[i]), ptr(z1[i]), Ns[i]) for i in range(2)])
-    check(lib.vqaf_softmax_wsum_multi(ctypes.cast(fm, ctypes.c_void_p), 2, B, D, H, dtype_code(seqs[0]), st), "fwd")
+    side = torch.ones(5000, **f32)  # a range cleared on the side: exactly the elements asked for
+    check(lib.vqaf_softmax_wsum_multi(ctypes.cast(fm, ctypes.c_void_p), 2, B, D, H, dtype_code(seqs[0]),
+                                      ptr(side[4:]), 4001, st), "fwd")
+    assert float(side[:4].sum()) == 4.0 and float(side[4:4005].abs().sum()) == 0.0 and float(side[4005:].sum()) == 995.0
     for i, n in enumerate(Ns):
         p0, z0 = torch.empty(B, H, n, **f32), torch.empty(B, H, D, **f32)
         check(lib.vqaf_softmax_heads(ptr(ss[i]), B, n, H, ptr(p0), st), "softmax")
@@ -198,18 +201,6 @@ def test_fused_token_kernels_are_bit_identical_to_the_separate_launches(dev, dty
     bm = (_lib.DenseBwdMod * 2)(*[_lib.DenseBwdMod(ptr(seqs[i]), ptr(p1[i]), ptr(dps[i]), ptr(us[i]), ptr(ts[i]),
                                                    ptr(z1[i]) if i == 0 else None, None, Ns[i]) for i in range(2)])
     assert lib.vqaf_token_bwd_multi(ctypes.cast(bm, ctypes.c_void_p), 2, B, D, H, dtype_code(seqs[0]), st) != 0
-    # column sums: f32 and bf16 sources, a pitch wider than the summed columns
-    rows, cols = 700, 200
-    a = torch.randn(rows, 2 * cols, device=dev, generator=gen).to(dtype)
-    b_ = torch.randn(rows, cols, device=dev, generator=gen)
-    dst = torch.zeros(3, cols, **f32)
-    srcs = [(a, 0, 2 * cols), (a, cols, 2 * cols), (b_, 0, cols)]
-    check(lib.vqaf_colsum_multi(3, (ctypes.c_void_p * 3)(*[t.data_ptr() + o * t.element_size() for t, o, _ in srcs]),
-                                (ctypes.c_int * 3)(*[dtype_code(t) for t, _, _ in srcs]),
-                                (ctypes.c_long * 3)(*[ld for _, _, ld in srcs]),
-                                (ctypes.c_void_p * 3)(*[ptr(dst[i]) for i in range(3)]), rows, cols, st), "colsum")
-    want = torch.stack([a[:, :cols].double().sum(0), a[:, cols:].double().sum(0), b_.double().sum(0)])
-    assert float((dst.double() - want).abs().max()) < 1e-3
     # two equal-shaped products in one launch against one launch each
     M, N, K = 40, 96, 512
     As = [torch.randn(M, K, device=dev, generator=gen) for _ in range(2)]
@@ -222,3 +213,30 @@ def test_fused_token_kernels_are_bit_identical_to_the_separate_launches(dev, dty
     for i in range(2):
         want = 0.5 * As[i].double() @ Bs[i].double()
         assert float((C[i].double() - want).abs().max()) < 1e-3
+    # different products in one launch: mixed shapes, operand types, strides, a bias, a batched problem and a
+    # column sum written as a product with a row of ones (all strides zero)
+    a1 = torch.randn(70, 300, device=dev, generator=gen).to(dtype)          # (M,K) k-contiguous
+    b1 = torch.randn(300, 130, device=dev, generator=gen)                   # (K,N) n-contiguous
+    bias1 = torch.randn(130, device=dev, generator=gen)
+    a2 = torch.randn(256, 48, device=dev, generator=gen)                    # read as A^T: (K,M) storage
+    b2 = torch.randn(256, 96, device=dev, generator=gen).to(dtype)
+    a3 = torch.randn(4, 33, 64, device=dev, generator=gen)                  # batched, G = 4
+    b3 = torch.randn(4, 64, 40, device=dev, generator=gen)
+    ones = torch.ones(4, **f32)
+    x4 = torch.randn(700, 200, device=dev, generator=gen).to(dtype)
+    c1, c2, c3, c4 = (torch.zeros(*sh, **f32) for sh in ((70, 130), (48, 96), (4, 33, 40), (200,)))
+    descs = (_lib.GemmDesc * 4)(
+        _lib.GemmDesc(ptr(a1), ptr(b1), ptr(bias1), ptr(c1), 0, 300, 1, 0, 130, 1, 0, 0, 130,
+                      dtype_code(a1), _lib.F32, _lib.F32, 1, 70, 130, 300, 0.5),
+        _lib.GemmDesc(ptr(a2), ptr(b2), None, ptr(c2), 0, 1, 48, 0, 96, 1, 0, 0, 96,
+                      _lib.F32, dtype_code(b2), _lib.F32, 1, 48, 96, 256, 1.0),
+        _lib.GemmDesc(ptr(a3), ptr(b3), None, ptr(c3), 33 * 64, 64, 1, 64 * 40, 40, 1, 0, 33 * 40, 40,
+                      _lib.F32, _lib.F32, _lib.F32, 4, 33, 40, 64, 2.0),
+        _lib.GemmDesc(ptr(ones), ptr(x4), None, ptr(c4), 0, 0, 0, 0, 200, 1, 0, 0, 200,
+                      _lib.F32, dtype_code(x4), _lib.F32, 1, 1, 200, 700, 1.0))
+    check(lib.vqaf_gemm_f32_group(4, ctypes.cast(descs, ctypes.c_void_p), st), "gemm group")
+    want = (0.5 * a1.double() @ b1.double() + bias1.double(), a2.double().t() @ b2.double(),
+            2.0 * torch.bmm(a3.double(), b3.double()), x4.double().sum(0))
+    for got, w in zip((c1, c2, c3, c4), want):
+        assert float((got.double() - w).abs().max()) < 2e-4 * max(1.0, float(w.abs().max()))
+    assert lib.vqaf_gemm_f32_group(13, ctypes.cast(descs, ctypes.c_void_p), st) != 0

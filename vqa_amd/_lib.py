@@ -55,6 +55,15 @@ class FusedMod(ctypes.Structure):
                 ("adv_mode", c_int), ("k_adv", c_int), ("col0", c_int), ("noise_counter_offset", c_int)]
 
 
+class GemmDesc(ctypes.Structure):
+    """vqaf_gemm_desc of include/vqaf.h."""
+    _fields_ = [("A", c_void_p), ("Bm", c_void_p), ("bias", c_void_p), ("C", c_void_p),
+                ("a_sg", c_long), ("a_sm", c_long), ("a_sk", c_long), ("b_sg", c_long), ("b_sk", c_long),
+                ("b_sn", c_long), ("bias_sg", c_long), ("c_sg", c_long), ("c_sm", c_long),
+                ("a_dtype", c_int), ("b_dtype", c_int), ("bias_dtype", c_int),
+                ("G", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("alpha", c_float)]
+
+
 class DenseFwdMod(ctypes.Structure):
     """vqaf_dense_fwd_mod of include/vqaf.h."""
     _fields_ = [("seq", c_void_p), ("s", c_void_p), ("p", c_void_p), ("z", c_void_p), ("N", c_int)]
@@ -125,9 +134,9 @@ SIGNATURES = {
     "vqaf_gemm_f32_atomic_sets": (c_int, [c_int, _P, c_int, c_long, c_long, c_long, _P, c_int, c_long, c_long, c_long,
                                           _P, c_int, c_long, _P, c_long, c_long, c_int, c_int, c_int, c_int,
                                           c_float, c_int, _P]),
-    "vqaf_softmax_wsum_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "vqaf_gemm_f32_group": (c_int, [c_int, _P, _P]),
+    "vqaf_softmax_wsum_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "vqaf_token_bwd_multi": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "vqaf_colsum_multi": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int, _P]),
     "vqaf_gemm_bf16_supported": (c_int, [c_long, c_int, c_long, c_int, c_int, c_int, c_int]),
     "vqaf_clipped_sum_adamw_group": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_long, _P, c_float, c_float,
                                              _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),

@@ -276,6 +276,131 @@ int gemm_launch(const GemmSets& sets, int nsets, int a_dtype, long a_sg, long a_
 }
 
 
+// ---- Several DIFFERENT small products in one launch ------------------------------------------------------
+// The backward of the dense co-attention has groups of short products that do not depend on each other (an
+// input gradient and two weight gradients of one incoming gradient, ...).  Each is a few microseconds of
+// load -> MFMA -> atomic add, and launches on one stream do not overlap, so they share a launch: every problem
+// brings its own shape, strides, operand types and staging modes, a workgroup finds its problem from the
+// running tile count, and the body is gemm_f32_kernel's with the staging mode chosen at run time (uniform per
+// workgroup).  Outputs are ADDED into C (the caller provides it zero-filled); long contractions are split over
+// workgroups with f32 atomics, as in vqaf_gemm_f32_atomic.
+constexpr int GEMM_MAX_GROUP = 12;
+struct GemmProb {
+  const void* A;
+  const void* Bm;
+  const void* bias;
+  float* C;
+  long a_sg, a_sm, a_sk, b_sg, b_sk, b_sn, bias_sg, c_sg, c_sm;
+  int G, M, N, K;
+  float alpha;
+  int amode, bmode, a_bf16, b_bf16, bias_bf16;
+  int splits, k_per_split, tiles_x, tiles_y;
+  int wg_begin;  // first workgroup of this problem
+};
+struct GemmGroupArgs {
+  GemmProb p[GEMM_MAX_GROUP];
+  int n;
+};
+
+template <bool BF16>
+__device__ __forceinline__ void fetch_tile_rt(int mode, const void* p, long base, long sx, long sk, int x0, int X,
+                                              int k0, int K, int tid, u32x4 (&r)[GVECS]) {
+  if (mode == G_KVEC) fetch_tile<G_KVEC, BF16>(p, base, sx, sk, x0, X, k0, K, tid, r);
+  else if (mode == G_XVEC) fetch_tile<G_XVEC, BF16>(p, base, sx, sk, x0, X, k0, K, tid, r);
+  else fetch_tile<G_SCALAR, BF16>(p, base, sx, sk, x0, X, k0, K, tid, r);
+}
+__device__ __forceinline__ void fetch_tile_any(int mode, int bf16, const void* p, long base, long sx, long sk, int x0,
+                                               int X, int k0, int K, int tid, u32x4 (&r)[GVECS]) {
+  if (bf16) fetch_tile_rt<true>(mode, p, base, sx, sk, x0, X, k0, K, tid, r);
+  else fetch_tile_rt<false>(mode, p, base, sx, sk, x0, X, k0, K, tid, r);
+}
+template <bool BF16>
+__device__ __forceinline__ void store_tile_rt(int mode, float (*T)[GP], int tid, const u32x4 (&r)[GVECS], int x0, int X,
+                                              int k0, int K) {
+  if (mode == G_KVEC) store_tile<G_KVEC, BF16>(T, tid, r, x0, X, k0, K);
+  else if (mode == G_XVEC) store_tile<G_XVEC, BF16>(T, tid, r, x0, X, k0, K);
+  else store_tile<G_SCALAR, BF16>(T, tid, r, x0, X, k0, K);
+}
+__device__ __forceinline__ void store_tile_any(int mode, int bf16, float (*T)[GP], int tid, const u32x4 (&r)[GVECS],
+                                               int x0, int X, int k0, int K) {
+  if (bf16) store_tile_rt<true>(mode, T, tid, r, x0, X, k0, K);
+  else store_tile_rt<false>(mode, T, tid, r, x0, X, k0, K);
+}
+
+__global__ void __launch_bounds__(GTHREADS)
+gemm_f32_group_kernel(GemmGroupArgs args) {
+  __shared__ float As[2][GK][GP];
+  __shared__ float Bs[2][GK][GP];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_MAX_GROUP; ++i)
+    if (i < args.n && (int)blockIdx.x >= args.p[i].wg_begin) pi = i;
+  const GemmProb& P = args.p[pi];
+  int local = blockIdx.x - P.wg_begin;
+  const int tx = local % P.tiles_x;
+  local /= P.tiles_x;
+  const int ty = local % P.tiles_y;
+  const int z = local / P.tiles_y;
+  const int kz = z % P.splits, g = z / P.splits;
+  const int M = P.M, N = P.N;
+  const int k_lo = kz * P.k_per_split;
+  const int K = min(P.K, k_lo + P.k_per_split);
+  const void* __restrict__ A = P.A;
+  const void* __restrict__ Bm = P.Bm;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = ty * GT, n0 = tx * GT;
+  const int amode = P.amode, bmode = P.bmode, abf = P.a_bf16, bbf = P.b_bf16;
+  const long a_sm = P.a_sm, a_sk = P.a_sk, b_sn = P.b_sn, b_sk = P.b_sk;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int gn = n0 + wn * 32 + (lane & 31);
+  float bias_v = 0.f;
+  if (P.bias != nullptr && kz == 0 && gn < N)
+    bias_v = P.bias_bf16 ? load1<true>(P.bias, (size_t)((long)g * P.bias_sg + gn))
+                         : load1<false>(P.bias, (size_t)((long)g * P.bias_sg + gn));
+  const long abase = (long)g * P.a_sg, bbase = (long)g * P.b_sg;
+  u32x4 ra[2][GVECS], rb[2][GVECS];
+  const int stages = (K - k_lo + GK - 1) / GK;
+  fetch_tile_any(amode, abf, A, abase, a_sm, a_sk, m0, M, k_lo, K, tid, ra[0]);
+  fetch_tile_any(bmode, bbf, Bm, bbase, b_sn, b_sk, n0, N, k_lo, K, tid, rb[0]);
+  fetch_tile_any(amode, abf, A, abase, a_sm, a_sk, m0, M, k_lo + GK, K, tid, ra[1]);
+  fetch_tile_any(bmode, bbf, Bm, bbase, b_sn, b_sk, n0, N, k_lo + GK, K, tid, rb[1]);
+  store_tile_any(amode, abf, As[0], tid, ra[0], m0, M, k_lo, K);
+  store_tile_any(bmode, bbf, Bs[0], tid, rb[0], n0, N, k_lo, K);
+  __syncthreads();
+  const int stages2 = (stages + 1) & ~1;
+#pragma unroll 1
+  for (int s = 0; s < stages2; s += 2) {
+#pragma unroll
+    for (int PP = 0; PP < 2; ++PP) {
+      const int t = s + PP;
+      fetch_tile_any(amode, abf, A, abase, a_sm, a_sk, m0, M, k_lo + (t + 2) * GK, K, tid, ra[PP]);
+      fetch_tile_any(bmode, bbf, Bm, bbase, b_sn, b_sk, n0, N, k_lo + (t + 2) * GK, K, tid, rb[PP]);
+      float af[GK / 2], bf[GK / 2];
+#pragma unroll
+      for (int i = 0; i < GK / 2; ++i) {
+        af[i] = As[PP][2 * i + (lane >> 5)][wm * 32 + (lane & 31)];
+        bf[i] = Bs[PP][2 * i + (lane >> 5)][wn * 32 + (lane & 31)];
+      }
+#pragma unroll
+      for (int i = 0; i < GK / 2; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[i], acc, 0, 0, 0);
+      store_tile_any(amode, abf, As[PP ^ 1], tid, ra[PP ^ 1], m0, M, k_lo + (t + 1) * GK, K);
+      store_tile_any(bmode, bbf, Bs[PP ^ 1], tid, rb[PP ^ 1], n0, N, k_lo + (t + 1) * GK, K);
+      __syncthreads();
+    }
+  }
+  float* const c0 = P.C + (long)g * P.c_sg + gn;
+  const int gm0 = m0 + wm * 32 + 4 * (lane >> 5);
+  const float alpha = P.alpha;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gm = gm0 + (r & 3) + 8 * (r >> 2);
+    if (gm < M && gn < N) atomicAdd(c0 + (long)gm * P.c_sm, alpha * acc[r] + bias_v);
+  }
+}
+
 // ---- Query fold with bf16 operands (bf16 queries, bf16 in_proj, head width 64, D = 512) on the bf16
 // matrix cores, one launch.  A product of two bf16 values is exact in f32, so
 //   qproj = q Wq_h^T + bq_h            (one bf16 MFMA per 32 k, f32 accumulation)
@@ -504,6 +629,53 @@ extern "C" int vqaf_gemm_f32_atomic_sets(int n_sets, const void* const* A_host, 
   sets.gper = G;
   return gemm_launch(sets, n_sets, a_dtype, a_sg, a_sm, a_sk, b_dtype, b_sg, b_sk, b_sn, bias_dtype, bias_sg, c_sg,
                      c_sm, G, M, N, K, alpha, beta_one, (hipStream_t)stream, true);
+}
+
+extern "C" int vqaf_gemm_f32_group(int n, const vqaf_gemm_desc* probs_host, vqaf_stream_t stream) {
+  VQAF_ENTRY();
+  VQAF_REQUIRE(probs_host != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(n > 0 && n <= GEMM_MAX_GROUP, VQAF_E_SHAPE);
+  GemmGroupArgs args = {};
+  args.n = n;
+  long total_tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const vqaf_gemm_desc& d = probs_host[i];
+    total_tiles += (long)((d.N + GT - 1) / GT) * ((d.M + GT - 1) / GT) * d.G;
+  }
+  int wg = 0;
+  for (int i = 0; i < n; ++i) {
+    const vqaf_gemm_desc& d = probs_host[i];
+    VQAF_REQUIRE(d.A != nullptr && d.Bm != nullptr && d.C != nullptr, VQAF_E_NULL);
+    VQAF_REQUIRE(vqaf_dtype_ok(d.a_dtype) && vqaf_dtype_ok(d.b_dtype) && (d.bias == nullptr || vqaf_dtype_ok(d.bias_dtype)),
+                 VQAF_E_DTYPE);
+    VQAF_REQUIRE(d.G > 0 && d.M > 0 && d.N > 0 && d.K > 0, VQAF_E_SHAPE);
+    GemmProb& P = args.p[i];
+    P.A = d.A; P.Bm = d.Bm; P.bias = d.bias; P.C = d.C;
+    P.a_sg = d.a_sg; P.a_sm = d.a_sm; P.a_sk = d.a_sk;
+    P.b_sg = d.b_sg; P.b_sk = d.b_sk; P.b_sn = d.b_sn;
+    P.bias_sg = d.bias_sg; P.c_sg = d.c_sg; P.c_sm = d.c_sm;
+    P.G = d.G; P.M = d.M; P.N = d.N; P.K = d.K;
+    P.alpha = d.alpha;
+    P.amode = pick_mode(d.A, d.a_dtype, d.a_sg, d.a_sm, d.a_sk, d.M, d.K);
+    P.bmode = pick_mode(d.Bm, d.b_dtype, d.b_sg, d.b_sn, d.b_sk, d.N, d.K);
+    P.a_bf16 = d.a_dtype == VQAF_BF16;
+    P.b_bf16 = d.b_dtype == VQAF_BF16;
+    P.bias_bf16 = d.bias_dtype == VQAF_BF16;
+    P.tiles_x = (d.N + GT - 1) / GT;
+    P.tiles_y = (d.M + GT - 1) / GT;
+    // the whole group should fill the chip about once: long contractions are split over workgroups
+    const long tiles = (long)P.tiles_x * P.tiles_y * d.G;
+    int splits = 1;
+    if (total_tiles < 256 && d.K >= 4 * GK)
+      while (splits < 16 && total_tiles * splits < 512 && d.K / (splits * 2) >= 2 * GK) splits *= 2;
+    P.splits = splits;
+    P.k_per_split = ((d.K + splits - 1) / splits + GK - 1) / GK * GK;
+    P.wg_begin = wg;
+    VQAF_REQUIRE(tiles * splits < (1l << 24), VQAF_E_SHAPE);
+    wg += (int)(tiles * splits);
+  }
+  hipLaunchKernelGGL(gemm_f32_group_kernel, dim3(wg), dim3(GTHREADS), 0, (hipStream_t)stream, args);
+  VQAF_LAUNCH_CHECK();
 }
 
 // u_i (B,H,D) for several (query, in_proj) pairs of one shape: two launches in total (see

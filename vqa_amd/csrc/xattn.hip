@@ -407,8 +407,13 @@ __device__ __forceinline__ void xa_weighted_sum(const void* __restrict__ seq, co
 
 template <bool BF16, int HP>
 __global__ void __launch_bounds__(XA_THREADS)
-softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H) {
+softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H, float* __restrict__ zero_ptr, unsigned int zero_count) {
   extern __shared__ __attribute__((aligned(16))) float xsm[];
+  {  // a range cleared on the side (outputs that the launches behind this one build with atomic adds)
+    const unsigned int nwg = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    for (unsigned int i = wg * XA_THREADS + threadIdx.x; i < zero_count; i += nwg * XA_THREADS) zero_ptr[i] = 0.f;
+  }
   const XaFwdMod& M = mods.m[blockIdx.z];
   const int N = M.N, b = blockIdx.y, tid = threadIdx.x;
   float* cs = xsm;                                  // [N][HP]
@@ -534,35 +539,6 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
     }
   }
   if constexpr (NEED_U) xa_weighted_sum<BF16, HP, 2 * HP>(M.seq, cs, red, b, N, D, H, M.du, first);
-}
-
-// dst[c] += sum_r src[r * ld + c] for up to XA_MAX_COLSUMS (source, destination) pairs in one launch (f32 or
-// bf16 sources; the destinations start from zero): the bias gradients of the dense branch.
-constexpr int XA_MAX_COLSUMS = 8;
-constexpr int XA_COLSUM_ROWS = 256;
-struct XaColsums {
-  const void* src[XA_MAX_COLSUMS];
-  float* dst[XA_MAX_COLSUMS];
-  long ld[XA_MAX_COLSUMS];
-  int bf16[XA_MAX_COLSUMS];
-};
-__global__ void __launch_bounds__(XA_THREADS)
-colsum_multi_kernel(XaColsums P, int rows, int cols) {
-  __shared__ float red[4][64];
-  const int k = blockIdx.z;
-  const void* src = P.src[k];
-  const long ld = P.ld[k];
-  const bool bf = P.bf16[k] != 0;
-  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int o = blockIdx.x * 64 + col;
-  const int r1 = min(rows, (int)(blockIdx.y + 1) * XA_COLSUM_ROWS);
-  float s0 = 0.f;
-  if (o < cols)
-    for (int r = blockIdx.y * XA_COLSUM_ROWS + rg; r < r1; r += 4)
-      s0 += bf ? load1<true>(src, (size_t)((long)r * ld + o)) : load1<false>(src, (size_t)((long)r * ld + o));
-  red[rg][col] = s0;
-  __syncthreads();
-  if (rg == 0 && o < cols) atomicAdd(&P.dst[k][o], (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]));
 }
 
 inline int pad_heads(int H) {
@@ -695,9 +671,10 @@ extern "C" int vqaf_token_outer(const float* ca, const float* va, const float* c
 constexpr size_t XA_MAX_LDS = 128 * 1024;
 
 extern "C" int vqaf_softmax_wsum_multi(const vqaf_dense_fwd_mod* mods_host, int n, int B, int D, int H, int dtype,
-                                       vqaf_stream_t stream) {
+                                       float* zero_ptr, size_t zero_count, vqaf_stream_t stream) {
   VQAF_ENTRY();
-  VQAF_REQUIRE(mods_host != nullptr, VQAF_E_NULL);
+  VQAF_REQUIRE(mods_host != nullptr && (zero_count == 0 || zero_ptr != nullptr), VQAF_E_NULL);
+  VQAF_REQUIRE(zero_count < (1ull << 32), VQAF_E_SHAPE);
   VQAF_REQUIRE(vqaf_dtype_ok(dtype), VQAF_E_DTYPE);
   VQAF_REQUIRE(n > 0 && n <= XA_MAX_MODS && B > 0 && B <= 65535 && D > 0 && H > 0 && H <= 8, VQAF_E_SHAPE);
   VQAF_REQUIRE(D % 8 == 0, VQAF_E_ALIGN);
@@ -717,7 +694,7 @@ extern "C" int vqaf_softmax_wsum_multi(const vqaf_dense_fwd_mod* mods_host, int 
   const dim3 grid((D + XA_SLW - 1) / XA_SLW, B, n), block(XA_THREADS);
   hipStream_t st = (hipStream_t)stream;
 #define XA_EXTRA
-  XA_BY_DT_HP(softmax_wsum_multi_kernel, grid, block, smem, st, mods, D, H);
+  XA_BY_DT_HP(softmax_wsum_multi_kernel, grid, block, smem, st, mods, D, H, zero_ptr, (unsigned int)zero_count);
 #undef XA_EXTRA
   VQAF_LAUNCH_CHECK();
 }
@@ -762,26 +739,5 @@ extern "C" int vqaf_token_bwd_multi(const vqaf_dense_bwd_mod* mods_host, int n, 
     XA_BY_DT_HP(token_bwd_multi_kernel, grid, block, smem, st, mods, D, H);
 #undef XA_EXTRA
   }
-  VQAF_LAUNCH_CHECK();
-}
-
-extern "C" int vqaf_colsum_multi(int n, const void* const* src_host, const int* src_dtype_host, const long* ld_host,
-                                 float* const* dst_host, int rows, int cols, vqaf_stream_t stream) {
-  VQAF_ENTRY();
-  VQAF_REQUIRE(src_host && src_dtype_host && ld_host && dst_host, VQAF_E_NULL);
-  VQAF_REQUIRE(n > 0 && n <= XA_MAX_COLSUMS && rows > 0 && cols > 0, VQAF_E_SHAPE);
-  XaColsums P = {};
-  for (int i = 0; i < n; ++i) {
-    VQAF_REQUIRE(src_host[i] && dst_host[i], VQAF_E_NULL);
-    VQAF_REQUIRE(vqaf_dtype_ok(src_dtype_host[i]), VQAF_E_DTYPE);
-    VQAF_REQUIRE(ld_host[i] >= cols, VQAF_E_SHAPE);
-    P.src[i] = src_host[i];
-    P.dst[i] = dst_host[i];
-    P.ld[i] = ld_host[i];
-    P.bf16[i] = src_dtype_host[i] == VQAF_BF16;
-  }
-  const dim3 grid((cols + 63) / 64, (rows + XA_COLSUM_ROWS - 1) / XA_COLSUM_ROWS, n);
-  VQAF_REQUIRE(grid.y <= 65535, VQAF_E_SHAPE);
-  hipLaunchKernelGGL(colsum_multi_kernel, grid, dim3(XA_THREADS), 0, (hipStream_t)stream, P, rows, cols);
   VQAF_LAUNCH_CHECK();
 }

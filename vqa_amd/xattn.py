@@ -10,7 +10,6 @@ as the reference's module does.
 """
 from __future__ import annotations
 
-import contextlib
 import math
 
 import torch
@@ -216,21 +215,6 @@ class _DenseSingleQuery(torch.autograd.Function):
                 cast(d_bin, bid), cast(d_wout, wod), cast(d_bout, bod), None)
 
 
-OVERLAP_WEIGHT_GRADS = True  # _DenseCoAttention.backward: weight gradients beside the token passes (second stream)
-_SIDE_STREAMS: dict = {}
-
-
-def _side_stream(device):
-    """A second stream of `device` (module level: an autograd function holds no state); None while a graph is
-    being captured before the stream exists (a stream cannot be created then)."""
-    st = _SIDE_STREAMS.get(device.index)
-    if st is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        st = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
-    return st
-
-
 def _gemm_sets(A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha=1.0, bias=None, bias_sg=0):
     """_gemm for several problems of ONE shape, stride set and dtype set in one launch: A, Bm, C (and bias)
     are lists of (tensor, element offset) pairs, one per problem.  The outputs are ADDED into C, which the
@@ -251,6 +235,46 @@ def _gemm_sets(A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha=1.0, bias=None, bias_s
         n, addrs(A), code(at), a_s[0], a_s[1], a_s[2], addrs(Bm), code(bt), b_s[0], b_s[1], b_s[2],
         addrs(bias) if bias is not None else None, code(bias[0][0]) if bias is not None else _lib.F32, bias_sg,
         addrs(C), c_s[0], c_s[1], G, M, N, K, float(alpha), 1, stream_ptr(ct.device)), "vqaf_gemm_f32_atomic_sets")
+
+
+_ONES: dict = {}
+
+
+def _ones(dev):
+    """A few f32 ones on `dev`: with zero strides they are the all-ones operand that turns a column sum into
+    one more problem of a grouped product launch."""
+    t = _ONES.get(dev)
+    if t is None:
+        t = _ONES[dev] = torch.ones(4, dtype=torch.float32, device=dev)
+    return t
+
+
+def _prob(A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha=1.0, bias=None, bias_sg=0):
+    """One problem of _gemm_group: the arguments of _gemm."""
+    return (A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha, bias, bias_sg)
+
+
+def _gemm_group(probs):
+    """Up to 12 different products (see _gemm for the arguments of each) in ONE launch, each added into its
+    zero-filled C: products that do not depend on each other share the launch instead of occupying the
+    stream one after the other."""
+    def addr(pair):
+        t, off = pair
+        return t.data_ptr() + off * t.element_size()
+
+    def code(t):
+        return _lib.BF16 if t.dtype == torch.bfloat16 else _lib.F32
+
+    arr = (_lib.GemmDesc * len(probs))()
+    for i, (A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha, bias, bias_sg) in enumerate(probs):
+        assert C[0].dtype == torch.float32
+        arr[i] = _lib.GemmDesc(addr(A), addr(Bm), addr(bias) if bias is not None else None, addr(C),
+                               a_s[0], a_s[1], a_s[2], b_s[0], b_s[1], b_s[2], bias_sg, c_s[0], c_s[1],
+                               code(A[0]), code(Bm[0]), code(bias[0]) if bias is not None else _lib.F32,
+                               G, M, N, K, float(alpha))
+    import ctypes
+    check(load().vqaf_gemm_f32_group(len(probs), ctypes.cast(arr, ctypes.c_void_p), stream_ptr(probs[0][4][0].device)),
+          "vqaf_gemm_f32_group")
 
 
 class _DenseCoAttention(torch.autograd.Function):
@@ -292,9 +316,11 @@ class _DenseCoAttention(torch.autograd.Function):
         p = [torch.empty(B, H, n, **f32) for n in Ns]
         fm = (_lib.DenseFwdMod * nb)(*[_lib.DenseFwdMod(ptr(seq_c[i]), ptr(s[i]), ptr(p[i]), ptr(z[i]), Ns[i])
                                        for i in range(nb)])
-        check(lib.vqaf_softmax_wsum_multi(ctypes.cast(fm, ctypes.c_void_p), nb, B, E, H, dtype_code(seq_c[0]), st),
-              "vqaf_softmax_wsum_multi")
-        attn, out = _zeroed(dev, (nb, B, E), (B, nb * E))
+        # (the same launch clears attn and out, which the two projections below build with atomic adds)
+        zbuf = torch.empty(2 * nb * B * E, **f32)
+        attn, out = zbuf[:nb * B * E].view(nb, B, E), zbuf[nb * B * E:].view(B, nb * E)
+        check(lib.vqaf_softmax_wsum_multi(ctypes.cast(fm, ctypes.c_void_p), nb, B, E, H, dtype_code(seq_c[0]),
+                                          ptr(zbuf), zbuf.numel(), st), "vqaf_softmax_wsum_multi")
         # attn_i[:, head h] = z_i[:,h,:] Wv_i[head h, :]^T + bv_i[head h]
         _gemm_sets([(z[i], 0) for i in range(nb)], (E, H * E, 1), [(w_in[i], 2 * E * E) for i in range(nb)],
                    (dh * E, 1, E), [(attn[i], 0) for i in range(nb)], (dh, E), H, B, dh, E,
@@ -337,25 +363,24 @@ class _DenseCoAttention(torch.autograd.Function):
         # through the output projection: d_attn_i = g[:, i*E:(i+1)*E] Wout_i
         _gemm_sets([(g, i * E) for i in rng], (0, nb * E, 1), [(w_out[i], 0) for i in rng], (0, E, 1),
                    [(d_attn[i], 0) for i in rng], (0, E), 1, B, E, E)
-        # The products that depend only on d_attn and on tensors of the forward pass (two of the four weight
-        # gradients) run on a second stream beside the token passes: they are short launches that leave most of
-        # the chip idle, and the token kernels that follow on this stream do not need them.
-        main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if (OVERLAP_WEIGHT_GRADS and need_par) else None
-        side_ctx = contextlib.nullcontext()
-        if side is not None:
-            side.wait_stream(main)
-            side_ctx = torch.cuda.stream(side)
-        if need_par:
-            with side_ctx:
+        # Everything that follows from d_attn alone shares ONE launch: launches on a stream do not overlap and each
+        # of these products is only a few microseconds of load -> MFMA -> atomic add.
+        ones = (_ones(dev), 0)
+        group = []
+        for i in rng:
+            # through the value projection: t_i[:,h,:] = d_attn_i[:, head h] Wv_i[head h, :]
+            group.append(_prob((d_attn[i], 0), (dh, E, 1), (w_in[i], 2 * E * E), (dh * E, E, 1), (t[i], 0), (E, H * E),
+                               H, B, E, dh))
+            if need_par:
                 # dWout_i = g_i^T attn_i;  dWv_i[head h rows] = d_attn_i[:, head h]^T z_i[:,h,:]
-                _gemm_sets([(g, i * E) for i in rng], (0, 1, nb * E), [(attn[i], 0) for i in rng], (0, E, 1),
-                           [(d_wout[i], 0) for i in rng], (0, E), 1, E, E, B)
-                _gemm_sets([(d_attn[i], 0) for i in rng], (dh, 1, E), [(z[i], 0) for i in rng], (E, H * E, 1),
-                           [(d_win[i], 2 * E * E) for i in rng], (dh * E, E), H, dh, E, B)
-        # through the value projection: t_i[:,h,:] = d_attn_i[:, head h] Wv_i[head h, :]
-        _gemm_sets([(d_attn[i], 0) for i in rng], (dh, E, 1), [(w_in[i], 2 * E * E) for i in rng], (dh * E, E, 1),
-                   [(t[i], 0) for i in rng], (E, H * E), H, B, E, dh)
+                group.append(_prob((g, i * E), (0, 1, nb * E), (attn[i], 0), (0, E, 1), (d_wout[i], 0), (0, E), 1, E, E, B))
+                group.append(_prob((d_attn[i], 0), (dh, 1, E), (z[i], 0), (E, H * E, 1), (d_win[i], 2 * E * E),
+                                   (dh * E, E), H, dh, E, B))
+                # bias gradients = column sums = products with a row of ones: of g (output bias) and of d_attn (value
+                # bias); the key bias shifts every score of a head alike and keeps its exact zero
+                group.append(_prob(ones, (0, 0, 0), (g, i * E), (0, nb * E, 1), (d_bout[i], 0), (0, E), 1, 1, E, B))
+                group.append(_prob(ones, (0, 0, 0), (d_attn[i], 0), (0, E, 1), (d_bin[i], 2 * E), (0, E), 1, 1, E, B))
+        _gemm_group(group)
         # through the token passes
         dp = [torch.empty(B, n, H, **f32) for n in Ns]
         sd = (_lib.ScoresDesc * nb)(*[_lib.ScoresDesc(ptr(seq_c[i]), ptr(t[i]), ptr(dp[i]), Ns[i]) for i in rng])
@@ -370,29 +395,26 @@ class _DenseCoAttention(torch.autograd.Function):
             check(lib.vqaf_token_bwd_multi(ctypes.cast(bm, ctypes.c_void_p), nb, B, E, H, dtype_code(seq_c[0]), st),
                   "vqaf_token_bwd_multi")
         if need_u:
-            # d_qp_i[:, head h] = du_i[:,h,:] Wk_i[head h, :]^T / sqrt(dh)
-            _gemm_sets([(du[i], 0) for i in rng], (E, H * E, 1), [(w_in[i], E * E) for i in rng], (dh * E, 1, E),
-                       [(d_qp[i], 0) for i in rng], (dh, E), H, B, dh, E, alpha=scale)
-        if need_q:
-            _gemm_sets([(d_qp[i], 0) for i in rng], (0, E, 1), [(w_in[i], 0) for i in rng], (0, E, 1),
-                       [(d_q[i], 0) for i in rng], (0, E), 1, B, E, E)
-        if need_par:
-            # dWk_i[head h rows] = qp_i[:, head h]^T du_i[:,h,:] / sqrt(dh);  dWq_i = d_qp_i^T query_i
-            _gemm_sets([(qp[i], 0) for i in rng], (dh, 1, E), [(du[i], 0) for i in rng], (E, H * E, 1),
-                       [(d_win[i], E * E) for i in rng], (dh * E, E), H, dh, E, B, alpha=scale)
-            _gemm_sets([(d_qp[i], 0) for i in rng], (0, 1, E), [(q_c[i], 0) for i in rng], (0, E, 1),
-                       [(d_win[i], 0) for i in rng], (0, E), 1, E, E, B)
-            if side is not None:
-                main.wait_stream(side)
-            # bias gradients: column sums of g, d_attn (value bias) and d_qp (query bias); the key bias shifts every
-            # score of a head alike and keeps its exact zero
-            srcs = [(g, i * E, nb * E) for i in rng] + [(d_attn[i], 0, E) for i in rng] + [(d_qp[i], 0, E) for i in rng]
-            dsts = [(d_bout[i], 0) for i in rng] + [(d_bin[i], 2 * E) for i in rng] + [(d_bin[i], 0) for i in rng]
-            k = len(srcs)
-            check(lib.vqaf_colsum_multi(
-                k, (ctypes.c_void_p * k)(*[t_.data_ptr() + o * t_.element_size() for t_, o, _ in srcs]),
-                (ctypes.c_int * k)(*[dtype_code(t_) for t_, _, _ in srcs]), (ctypes.c_long * k)(*[ld for _, _, ld in srcs]),
-                (ctypes.c_void_p * k)(*[t_.data_ptr() + o * 4 for t_, o in dsts]), B, E, st), "vqaf_colsum_multi")
+            group = []
+            for i in rng:
+                # d_qp_i[:, head h] = du_i[:,h,:] Wk_i[head h, :]^T / sqrt(dh)
+                group.append(_prob((du[i], 0), (E, H * E, 1), (w_in[i], E * E), (dh * E, 1, E), (d_qp[i], 0), (dh, E),
+                                   H, B, dh, E, alpha=scale))
+                if need_par:
+                    # dWk_i[head h rows] = qp_i[:, head h]^T du_i[:,h,:] / sqrt(dh)
+                    group.append(_prob((qp[i], 0), (dh, 1, E), (du[i], 0), (E, H * E, 1), (d_win[i], E * E), (dh * E, E),
+                                       H, dh, E, B, alpha=scale))
+            _gemm_group(group)
+            group = []
+            for i in rng:
+                if need_par:
+                    # dWq_i = d_qp_i^T query_i; the query bias gradient = column sums of d_qp
+                    group.append(_prob((d_qp[i], 0), (0, 1, E), (q_c[i], 0), (0, E, 1), (d_win[i], 0), (0, E), 1, E, E, B))
+                    group.append(_prob(ones, (0, 0, 0), (d_qp[i], 0), (0, E, 1), (d_bin[i], 0), (0, E), 1, 1, E, B))
+                if need_q:
+                    group.append(_prob((d_qp[i], 0), (0, E, 1), (w_in[i], 0), (0, E, 1), (d_q[i], 0), (0, E), 1, B, E, E))
+            if group:
+                _gemm_group(group)
         # hand back in the inputs' dtypes: when they all share one (the usual bf16 module), ONE cast of the block
         # of returned products serves every gradient
         want = {d for dts, n in zip(ctx.dtypes, need) for d, nd in zip(dts, (n[0], n[2], n[3], n[4], n[5])) if nd}
