@@ -64,8 +64,10 @@ def test_coattention_dense_vs_golden(dev, name, batched):
 @pytest.mark.parametrize("E,H,N,B,dtype", [(512, 8, 197, 3, torch.float32), (256, 4, 50, 5, torch.float32),
                                            (64, 1, 9, 2, torch.float32), (512, 8, 300, 4, torch.bfloat16),
                                            (128, 2, 33, 70, torch.bfloat16)])
-def test_attention_dense_full_gradients_vs_oracle(dev, E, H, N, B, dtype):
-    """Attention(use_pruning=False): every gradient element against autograd on the oracle."""
+@pytest.mark.parametrize("shared", [True, False])
+def test_attention_dense_full_gradients_vs_oracle(dev, E, H, N, B, dtype, shared):
+    """Attention(use_pruning=False): every gradient element against autograd on the oracle, on the
+    launch-sharing form (the default) and on the per-product chain."""
     from vqa_amd import fusion
     v_seq, v_global = gi.tokens(40 + N, B, N, E)
     q_seq, q_global = gi.tokens(41 + N, B, 12, E)
@@ -81,6 +83,7 @@ def test_attention_dense_full_gradients_vs_oracle(dev, E, H, N, B, dtype):
     m = fusion.Attention(embed_dim=E, num_heads=H, use_pruning=False)
     m.attention.load_state_dict(p)
     m = m.to(dev)
+    m.batch_launches = shared
     vs = v_seq.to(dev).to(dtype).requires_grad_()
     qg = q_global.to(dev).to(dtype).requires_grad_()
     out = m(vs, v_global.to(dev).to(dtype), q_seq.to(dev).to(dtype), qg)

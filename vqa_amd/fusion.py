@@ -185,6 +185,7 @@ class Attention(nn.Module):
         self.fuse_pool = True  # skip materialising the pruned tokens (same result)
         self.fuse_select = True  # scoring + selection + pooling of a sample in one workgroup (bf16 tokens)
         self.score_order = "fold"  # "reference": rank tokens with the reference's own operation order
+        self.batch_launches = True  # dense (non-pruning) mode: fused token passes and shared launches
         if use_pruning:
             # utils/fusion.py:141-146 passes no noise arguments, so the class defaults apply
             # (noise_injection=True, noise_scale=0.01, gaussian).
@@ -224,8 +225,13 @@ class Attention(nn.Module):
                 w = _scores(self.attention, q_global, v_seq)
                 attended_v = ops.mean_pool(self.pruning(v_seq, w, **inject))
         else:
-            from .xattn import single_query_attention
-            attended_v = single_query_attention(self.attention, q_global, v_seq)
+            from .xattn import dense_coattention, dense_coattention_supported, single_query_attention
+            if self.batch_launches and dense_coattention_supported((self.attention,), (q_global,), (v_seq,)):
+                # the launch-sharing form of the dense branch (softmax inside the token passes, independent
+                # products of the backward in shared launches), here with one branch
+                attended_v = dense_coattention((self.attention,), (q_global,), (v_seq,))
+            else:
+                attended_v = single_query_attention(self.attention, q_global, v_seq)
         return torch.cat([attended_v, q_global.to(attended_v.dtype)], dim=1)
 
 
