@@ -56,8 +56,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+// Two values in one instruction (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays a quiet NaN): the same
+// results as f32_to_bf16 for every non-NaN input at an eighth of the vector instructions.
+typedef float vqaf_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 vqaf_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(vqaf_f32x2{lo, hi}, vqaf_bf16x2));
 }
 
 // Loads 8 consecutive elements starting at element offset `e` (multiple of 8) as f32.

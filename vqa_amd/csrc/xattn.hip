@@ -250,6 +250,16 @@ token_outer_kernel(const float* __restrict__ ca, const float* __restrict__ va,
 //   token_bwd_multi_kernel      (p, dp) -> ds in LDS, du = sum_n ds x and grad_seq = ds u + p t, one pass
 // The arithmetic and the order of every sum are those of softmax_heads(_bwd)_kernel,
 // weighted_token_sum_kernel and token_outer_kernel, so the results are bit-identical to the separate launches.
+#ifdef XA_STAMPS  // developer build (make stamps): s_memrealtime stamps of token_bwd_multi_kernel's phases per workgroup
+__device__ unsigned long long xa_stamp_buf[8192 * 8];
+#define XA_STAMP(i)                                                                                        \
+  do {                                                                                                     \
+    const unsigned int wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);               \
+    if (threadIdx.x == 0 && wg_ < 8192) xa_stamp_buf[wg_ * 8 + (i)] = __builtin_amdgcn_s_memrealtime();     \
+  } while (0)
+#else
+#define XA_STAMP(i) do {} while (0)
+#endif
 constexpr int XA_MAX_MODS = 4;
 struct XaFwdMod {
   const void* seq;  // (B,N,D)
@@ -416,8 +426,11 @@ softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H, float* __restrict__ zero
   }
   const XaFwdMod& M = mods.m[blockIdx.z];
   const int N = M.N, b = blockIdx.y, tid = threadIdx.x;
-  float* cs = xsm;                                  // [N][HP]
-  float* red = xsm + (size_t)HP * N;                // [XA_THREADS * 8]
+  // a token's coefficients sit together; the row pitch (HP + 4 floats) spreads consecutive tokens over the LDS
+  // banks (with a pitch of HP floats, lanes that own consecutive tokens collide 8 ways on every access)
+  constexpr int CP = HP + 4;
+  float* cs = xsm;                                  // [N][CP]
+  float* red = xsm + (size_t)CP * N;                // [XA_THREADS * 8]
   float (*wred)[HP] = reinterpret_cast<float (*)[HP]>(red);  // the block reductions run before the sums use it
   float* stat = red + XA_THREADS * 8;               // [2][HP]
   const float* sb = M.s + (size_t)b * N * H;
@@ -430,7 +443,7 @@ softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H, float* __restrict__ zero
 #pragma unroll
     for (int h = 0; h < HP; ++h) {
       const float v = h < H ? sb[(size_t)n * H + h] : 0.f;
-      cs[n * HP + h] = v;
+      cs[n * CP + h] = v;
       if (h < H) m[h] = fmaxf(m[h], v);
     }
   xa_block_reduce<HP, true>(m, wred, stat);
@@ -440,19 +453,19 @@ softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H, float* __restrict__ zero
   for (int n = tid; n < N; n += XA_THREADS)
 #pragma unroll
     for (int h = 0; h < HP; ++h)
-      if (h < H) zz[h] += expf(cs[n * HP + h] - m[h]);
+      if (h < H) zz[h] += expf(cs[n * CP + h] - m[h]);
   xa_block_reduce<HP, false>(zz, wred, stat + HP);
   float* pb = M.p + (size_t)b * H * N;
   for (int n = tid; n < N; n += XA_THREADS)
 #pragma unroll
     for (int h = 0; h < HP; ++h)
       if (h < H) {
-        const float pv = expf(cs[n * HP + h] - m[h]) / stat[HP + h];
-        cs[n * HP + h] = pv;
+        const float pv = expf(cs[n * CP + h] - m[h]) / stat[HP + h];
+        cs[n * CP + h] = pv;
         if (blockIdx.x == 0) pb[(size_t)h * N + n] = pv;
       }
   __syncthreads();
-  xa_weighted_sum<BF16, HP, HP>(M.seq, cs, red, b, N, D, H, M.z, first);
+  xa_weighted_sum<BF16, HP, CP>(M.seq, cs, red, b, N, D, H, M.z, first);
 }
 
 template <bool BF16, int HP, bool NEED_U, bool NEED_SEQ>
@@ -461,12 +474,16 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
   extern __shared__ __attribute__((aligned(16))) float xsm[];
   const XaBwdMod& M = mods.m[blockIdx.z];
   const int N = M.N, b = blockIdx.y, tid = threadIdx.x, g = tid / XA_LPR, li = tid % XA_LPR;
-  float* cs = xsm;                                  // [N][2*HP]: ds_0..ds_{HP-1}, p_0..p_{HP-1}
-  float* red = xsm + (size_t)2 * HP * N;            // [XA_THREADS * 8]
+  // row pitch 2 * HP + 4 floats: consecutive tokens fall on different LDS banks (a pitch of 2 * HP floats makes
+  // the lanes of the staging loops collide 16 ways: 14 of this kernel's 16 us prologue at N = 577)
+  constexpr int CP = 2 * HP + 4;
+  float* cs = xsm;                                  // [N][CP]: ds_0..ds_{HP-1}, p_0..p_{HP-1}
+  float* red = xsm + (size_t)CP * N;                // [XA_THREADS * 8]
   float (*wred)[HP] = reinterpret_cast<float (*)[HP]>(red);
   float* stat = red + XA_THREADS * 8;               // [HP]
   const float* pb = M.p + (size_t)b * H * N;
   const float* dpb = M.dp + (size_t)b * N * H;
+  XA_STAMP(0);
   XaRaw<BF16> first[XA_WS_U];  // the first rows of the folded-query gradient's pass, requested up front
   if constexpr (NEED_U) xa_ws_fetch<BF16>(M.seq, b, N, D, g, first);
   float acc[HP];
@@ -477,16 +494,19 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
     for (int h = 0; h < HP; ++h) {
       const float pv = h < H ? pb[(size_t)h * N + n] : 0.f;
       const float dv = h < H ? dpb[(size_t)n * H + h] : 0.f;
-      cs[n * 2 * HP + HP + h] = pv;
-      cs[n * 2 * HP + h] = dv;
+      cs[n * CP + HP + h] = pv;
+      cs[n * CP + h] = dv;
       if (h < H) acc[h] = fmaf(pv, dv, acc[h]);
     }
+  XA_STAMP(4);
   xa_block_reduce<HP, false>(acc, wred, stat);
+  XA_STAMP(5);
   for (int n = tid; n < N; n += XA_THREADS)
 #pragma unroll
     for (int h = 0; h < HP; ++h)
-      if (h < H) cs[n * 2 * HP + h] = cs[n * 2 * HP + HP + h] * (cs[n * 2 * HP + h] - stat[h]);
+      if (h < H) cs[n * CP + h] = cs[n * CP + HP + h] * (cs[n * CP + h] - stat[h]);
   __syncthreads();
+  XA_STAMP(1);
   if constexpr (NEED_SEQ) {
     const int d0 = blockIdx.x * XA_SLW + li * 8;
     if (d0 < D) {
@@ -502,7 +522,7 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
         }
       }
       auto row = [&](int n, float (&o)[8]) {
-        const float* cw = cs + (size_t)n * 2 * HP;
+        const float* cw = cs + (size_t)n * CP;
         float w[2 * HP];
         if constexpr (HP >= 2) {
 #pragma unroll
@@ -538,7 +558,9 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
       }
     }
   }
-  if constexpr (NEED_U) xa_weighted_sum<BF16, HP, 2 * HP>(M.seq, cs, red, b, N, D, H, M.du, first);
+  XA_STAMP(2);
+  if constexpr (NEED_U) xa_weighted_sum<BF16, HP, CP>(M.seq, cs, red, b, N, D, H, M.du, first);
+  XA_STAMP(3);
 }
 
 inline int pad_heads(int H) {
@@ -689,7 +711,7 @@ extern "C" int vqaf_softmax_wsum_multi(const vqaf_dense_fwd_mod* mods_host, int 
     mods.m[i] = XaFwdMod{h.seq, h.s, h.p, h.z, h.N};
     n_max = h.N > n_max ? h.N : n_max;
   }
-  const size_t smem = ((size_t)HP * n_max + (size_t)XA_THREADS * 8 + 2 * HP) * sizeof(float);
+  const size_t smem = ((size_t)(HP + 4) * n_max + (size_t)XA_THREADS * 8 + 2 * HP) * sizeof(float);
   VQAF_REQUIRE(smem <= XA_MAX_LDS, VQAF_E_SHAPE);
   const dim3 grid((D + XA_SLW - 1) / XA_SLW, B, n), block(XA_THREADS);
   hipStream_t st = (hipStream_t)stream;
@@ -722,7 +744,7 @@ extern "C" int vqaf_token_bwd_multi(const vqaf_dense_bwd_mod* mods_host, int n, 
     mods.m[i] = XaBwdMod{h.seq, h.p, h.dp, h.u, h.t, h.du, h.grad_seq, h.N};
     n_max = h.N > n_max ? h.N : n_max;
   }
-  const size_t smem = ((size_t)2 * HP * n_max + (size_t)XA_THREADS * 8 + HP) * sizeof(float);
+  const size_t smem = ((size_t)(2 * HP + 4) * n_max + (size_t)XA_THREADS * 8 + HP) * sizeof(float);
   VQAF_REQUIRE(smem <= XA_MAX_LDS, VQAF_E_SHAPE);
   const dim3 grid((D + XA_SLW - 1) / XA_SLW, B, n), block(XA_THREADS);
   hipStream_t st = (hipStream_t)stream;
@@ -741,3 +763,9 @@ extern "C" int vqaf_token_bwd_multi(const vqaf_dense_bwd_mod* mods_host, int n, 
   }
   VQAF_LAUNCH_CHECK();
 }
+
+#ifdef XA_STAMPS
+extern "C" int vqaf_debug_xa_stamps(unsigned long long* host_out, size_t count) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(xa_stamp_buf), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -455,7 +455,7 @@ def dense_coattention_supported(mhas, queries, seqs) -> bool:
                 m.in_proj_weight.dtype not in (torch.float32, torch.bfloat16) or m.in_proj_bias is None or \
                 m.out_proj.bias is None:
             return False
-        if (2 * 8 * s.shape[1] + 2048 + 8) * 4 > 128 * 1024:
+        if ((2 * 8 + 4) * s.shape[1] + 2048 + 8) * 4 > 128 * 1024:
             return False
     return True
 
