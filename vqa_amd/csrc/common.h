@@ -49,12 +49,9 @@ __device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_floa
 __device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((unsigned int)h) << 16); }
 
-// Round-to-nearest-even f32 -> bf16; NaN stays NaN (quiet).
+// Round-to-nearest-even f32 -> bf16; NaN stays NaN (quiet).  One hardware conversion (v_cvt_pk_bf16_f32).
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  return (bf16_t)__builtin_bit_cast(unsigned short, (__bf16)f);
 }
 // Two values in one instruction (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays a quiet NaN): the same
 // results as f32_to_bf16 for every non-NaN input at an eighth of the vector instructions.
