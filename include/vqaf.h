@@ -432,8 +432,8 @@ int vqaf_gemm_f32_group(int n, const vqaf_gemm_desc* probs_host, vqaf_stream_t s
  * vqaf_softmax_wsum_multi also clears zero_count f32 at zero_ptr on the side (may be 0 / NULL; nothing the launch
  * reads or writes): the outputs that the projections behind it build with atomic adds.
  * du or grad_seq may be NULL (for every problem alike) when that gradient is not needed.  H <= 8,
- * D % 8 == 0, and the per-sample coefficients must fit 128 KiB of LDS ((H+4)*N*4, resp. (2*H+4)*N*4 bytes + 8 KiB,
- * H rounded up to a power of two). */
+ * D % 8 == 0, and the per-sample coefficients must fit 128 KiB of LDS ((H+4)*N*4, resp. (2*H+4)*N*4 bytes, H rounded
+ * up to a power of two). */
 typedef struct vqaf_dense_fwd_mod {
   const void* seq; /* (B,N,D) `dtype` */
   const float* s;  /* (B,N,H) raw head scores */

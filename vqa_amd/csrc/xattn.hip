@@ -9,6 +9,7 @@
 //   dp[n,h] = x_n . t_h  (t_h = Wv_h^T d_attn_h),  ds = p * (dp - sum_n p dp),
 //   y_h = sum_n ds[h,n] x_n  (= d u_h),  grad_seq[n,:] = sum_h ds[h,n] u_h + p[h,n] t_h.
 // Everything here is bandwidth-bound; the (B,H,D)-sized projections around it are small GEMMs.
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -430,22 +431,37 @@ softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H, float* __restrict__ zero
   // banks (with a pitch of HP floats, lanes that own consecutive tokens collide 8 ways on every access)
   constexpr int CP = HP + 4;
   float* cs = xsm;                                  // [N][CP]
-  float* red = xsm + (size_t)CP * N;                // [XA_THREADS * 8]
-  float (*wred)[HP] = reinterpret_cast<float (*)[HP]>(red);  // the block reductions run before the sums use it
-  float* stat = red + XA_THREADS * 8;               // [2][HP]
+  float* red = xsm;                                 // [XA_THREADS * 8]: the final fold, when cs has been consumed
+  float* small = xsm + max(CP * N, XA_THREADS * 8);
+  float (*wred)[HP] = reinterpret_cast<float (*)[HP]>(small);  // [waves][HP] of the block reductions
+  float* stat = small + (XA_THREADS / 64) * HP;     // [2][HP]
   const float* sb = M.s + (size_t)b * N * H;
   XaRaw<BF16> first[XA_WS_U];  // the first rows travel while the softmax is computed
   xa_ws_fetch<BF16>(M.seq, b, N, D, tid / XA_LPR, first);
   float m[HP], zz[HP];
 #pragma unroll
   for (int h = 0; h < HP; ++h) { m[h] = -INFINITY; zz[h] = 0.f; }
-  for (int n = tid; n < N; n += XA_THREADS)
+  for (int n0 = tid; n0 < N; n0 += 4 * XA_THREADS) {  // four tokens per thread and round, all loads requested first
+    float sv[4][HP];
 #pragma unroll
-    for (int h = 0; h < HP; ++h) {
-      const float v = h < H ? sb[(size_t)n * H + h] : 0.f;
-      cs[n * CP + h] = v;
-      if (h < H) m[h] = fmaxf(m[h], v);
+    for (int r = 0; r < 4; ++r) {
+      const int n = min(n0 + r * XA_THREADS, N - 1);
+#pragma unroll
+      for (int h = 0; h < HP; ++h) sv[r][h] = sb[(size_t)n * H + min(h, H - 1)];
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + r * XA_THREADS;
+      if (n < N) {
+#pragma unroll
+        for (int h = 0; h < HP; ++h) {
+          const float v = h < H ? sv[r][h] : 0.f;
+          cs[n * CP + h] = v;
+          if (h < H) m[h] = fmaxf(m[h], v);
+        }
+      }
+    }
+  }
   xa_block_reduce<HP, true>(m, wred, stat);
 #pragma unroll
   for (int h = 0; h < HP; ++h) m[h] = stat[h];
@@ -469,7 +485,7 @@ softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H, float* __restrict__ zero
 }
 
 template <bool BF16, int HP, bool NEED_U, bool NEED_SEQ>
-__global__ void __launch_bounds__(XA_THREADS)
+__global__ void __launch_bounds__(XA_THREADS, 3)  // three workgroups per CU: the short (text) problems run beside the long ones
 token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
   extern __shared__ __attribute__((aligned(16))) float xsm[];
   const XaBwdMod& M = mods.m[blockIdx.z];
@@ -478,26 +494,47 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
   // the lanes of the staging loops collide 16 ways: 14 of this kernel's 16 us prologue at N = 577)
   constexpr int CP = 2 * HP + 4;
   float* cs = xsm;                                  // [N][CP]: ds_0..ds_{HP-1}, p_0..p_{HP-1}
-  float* red = xsm + (size_t)CP * N;                // [XA_THREADS * 8]
-  float (*wred)[HP] = reinterpret_cast<float (*)[HP]>(red);
-  float* stat = red + XA_THREADS * 8;               // [HP]
+  float* red = xsm;                                 // [XA_THREADS * 8]: the final fold, when cs has been consumed
+  float* small = xsm + max(CP * N, XA_THREADS * 8);
+  float (*wred)[HP] = reinterpret_cast<float (*)[HP]>(small);  // [waves][HP] of the block reduction
+  float* stat = small + (XA_THREADS / 64) * HP;     // [HP]
   const float* pb = M.p + (size_t)b * H * N;
   const float* dpb = M.dp + (size_t)b * N * H;
   XA_STAMP(0);
-  XaRaw<BF16> first[XA_WS_U];  // the first rows of the folded-query gradient's pass, requested up front
-  if constexpr (NEED_U) xa_ws_fetch<BF16>(M.seq, b, N, D, g, first);
+  XaRaw<BF16> first[XA_WS_U];  // the first rows of the folded-query gradient's pass: requested up front when that
+  // pass follows the prologue directly, else after the token gradient (their registers are needed there)
+  if constexpr (NEED_U && !NEED_SEQ) xa_ws_fetch<BF16>(M.seq, b, N, D, g, first);
   float acc[HP];
 #pragma unroll
   for (int h = 0; h < HP; ++h) acc[h] = 0.f;
-  for (int n = tid; n < N; n += XA_THREADS)
+  // four tokens per thread and round: every load of a round is requested before the first is used (indices past
+  // the end are clamped, their values dropped), so a round costs one memory latency
+  for (int n0 = tid; n0 < N; n0 += 4 * XA_THREADS) {
+    float pv[4][HP], dv[4][HP];
 #pragma unroll
-    for (int h = 0; h < HP; ++h) {
-      const float pv = h < H ? pb[(size_t)h * N + n] : 0.f;
-      const float dv = h < H ? dpb[(size_t)n * H + h] : 0.f;
-      cs[n * CP + HP + h] = pv;
-      cs[n * CP + h] = dv;
-      if (h < H) acc[h] = fmaf(pv, dv, acc[h]);
+    for (int r = 0; r < 4; ++r) {
+      const int n = min(n0 + r * XA_THREADS, N - 1);
+#pragma unroll
+      for (int h = 0; h < HP; ++h) {
+        const int hc = min(h, H - 1);
+        pv[r][h] = pb[(size_t)hc * N + n];
+        dv[r][h] = dpb[(size_t)n * H + hc];
+      }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + r * XA_THREADS;
+      if (n < N) {
+#pragma unroll
+        for (int h = 0; h < HP; ++h) {
+          const float p_ = h < H ? pv[r][h] : 0.f, d_ = h < H ? dv[r][h] : 0.f;
+          cs[n * CP + HP + h] = p_;
+          cs[n * CP + h] = d_;
+          if (h < H) acc[h] = fmaf(p_, d_, acc[h]);
+        }
+      }
+    }
+  }
   XA_STAMP(4);
   xa_block_reduce<HP, false>(acc, wred, stat);
   XA_STAMP(5);
@@ -543,15 +580,9 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { o[2 * i] = o2[i].x; o[2 * i + 1] = o2[i].y; }
       };
-      int n = g;
-      for (; n + XA_ROWS < N; n += 2 * XA_ROWS) {
-        float o0[8], o1[8];
-        row(n, o0);
-        row(n + XA_ROWS, o1);
-        store8<BF16>(M.gseq, ((size_t)b * N + n) * D + d0, o0);
-        store8<BF16>(M.gseq, ((size_t)b * N + n + XA_ROWS) * D + d0, o1);
-      }
-      if (n < N) {
+      // one row at a time: with u and t of eight heads in registers (128 of them) a second row in flight would
+      // cost the third workgroup per CU
+      for (int n = g; n < N; n += XA_ROWS) {
         float o0[8];
         row(n, o0);
         store8<BF16>(M.gseq, ((size_t)b * N + n) * D + d0, o0);
@@ -559,6 +590,7 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
     }
   }
   XA_STAMP(2);
+  if constexpr (NEED_U && NEED_SEQ) xa_ws_fetch<BF16>(M.seq, b, N, D, g, first);
   if constexpr (NEED_U) xa_weighted_sum<BF16, HP, CP>(M.seq, cs, red, b, N, D, H, M.du, first);
   XA_STAMP(3);
 }
@@ -711,7 +743,7 @@ extern "C" int vqaf_softmax_wsum_multi(const vqaf_dense_fwd_mod* mods_host, int 
     mods.m[i] = XaFwdMod{h.seq, h.s, h.p, h.z, h.N};
     n_max = h.N > n_max ? h.N : n_max;
   }
-  const size_t smem = ((size_t)(HP + 4) * n_max + (size_t)XA_THREADS * 8 + 2 * HP) * sizeof(float);
+  const size_t smem = (std::max((size_t)(HP + 4) * n_max, (size_t)XA_THREADS * 8) + 6 * HP) * sizeof(float);
   VQAF_REQUIRE(smem <= XA_MAX_LDS, VQAF_E_SHAPE);
   const dim3 grid((D + XA_SLW - 1) / XA_SLW, B, n), block(XA_THREADS);
   hipStream_t st = (hipStream_t)stream;
@@ -744,7 +776,7 @@ extern "C" int vqaf_token_bwd_multi(const vqaf_dense_bwd_mod* mods_host, int n, 
     mods.m[i] = XaBwdMod{h.seq, h.p, h.dp, h.u, h.t, h.du, h.grad_seq, h.N};
     n_max = h.N > n_max ? h.N : n_max;
   }
-  const size_t smem = ((size_t)(2 * HP + 4) * n_max + (size_t)XA_THREADS * 8 + HP) * sizeof(float);
+  const size_t smem = (std::max((size_t)(2 * HP + 4) * n_max, (size_t)XA_THREADS * 8) + 5 * HP) * sizeof(float);
   VQAF_REQUIRE(smem <= XA_MAX_LDS, VQAF_E_SHAPE);
   const dim3 grid((D + XA_SLW - 1) / XA_SLW, B, n), block(XA_THREADS);
   hipStream_t st = (hipStream_t)stream;
