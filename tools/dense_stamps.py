@@ -30,8 +30,18 @@ gs = [torch.empty_like(s) for s in seqs]
 bm = (_lib.DenseBwdMod * 2)(*[_lib.DenseBwdMod(_lib.ptr(seqs[i]), _lib.ptr(ps[i]), _lib.ptr(dps[i]), _lib.ptr(us[i]),
                                                _lib.ptr(ts[i]), _lib.ptr(du[i]), _lib.ptr(gs[i]), Ns[i]) for i in range(2)])
 st = _lib.stream_ptr(dev)
+FWD = len(sys.argv) > 3 and sys.argv[3] == "fwd"  # stamps of softmax_wsum_multi_kernel instead (same slots:
+# start, coefficients ready, (unused), weighted sum done; 4/5 = scores staged / maximum reduced)
+if FWD:
+    ss = [torch.randn(B, n, H, device=dev, generator=gen) for n in Ns]
+    zs = [torch.empty(B, H, D, **f32) for _ in Ns]
+    fm = (_lib.DenseFwdMod * 2)(*[_lib.DenseFwdMod(_lib.ptr(seqs[i]), _lib.ptr(ss[i]), _lib.ptr(ps[i]), _lib.ptr(zs[i]), Ns[i])
+                                  for i in range(2)])
 for _ in range(3):
-    _lib.check(lib.vqaf_token_bwd_multi(ctypes.cast(bm, ctypes.c_void_p), 2, B, D, H, _lib.BF16, st), "bwd")
+    if FWD:
+        _lib.check(lib.vqaf_softmax_wsum_multi(ctypes.cast(fm, ctypes.c_void_p), 2, B, D, H, _lib.BF16, None, 0, st), "fwd")
+    else:
+        _lib.check(lib.vqaf_token_bwd_multi(ctypes.cast(bm, ctypes.c_void_p), 2, B, D, H, _lib.BF16, st), "bwd")
 torch.cuda.synchronize()
 nwg = 4 * B * 2
 buf = (ctypes.c_ulonglong * (nwg * 8))()

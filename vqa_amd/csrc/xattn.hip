@@ -282,6 +282,33 @@ struct XaBwdMod {
 };
 struct XaBwdMods { XaBwdMod m[XA_MAX_MODS]; };
 
+// HP consecutive floats of an LDS row (16-byte aligned when HP >= 4) as 16-byte accesses: eight lanes that own
+// consecutive rows of pitch HP + 4 or 2 * HP + 4 floats then touch disjoint banks, where 4-byte accesses to the
+// same column of consecutive rows collide four ways.
+template <int HP>
+__device__ __forceinline__ void xa_row_store(float* row, const float (&v)[HP]) {
+  if constexpr (HP >= 4) {
+#pragma unroll
+    for (int h = 0; h < HP; h += 4) *reinterpret_cast<f32x4*>(row + h) = f32x4{v[h], v[h + 1], v[h + 2], v[h + 3]};
+  } else {
+#pragma unroll
+    for (int h = 0; h < HP; ++h) row[h] = v[h];
+  }
+}
+template <int HP>
+__device__ __forceinline__ void xa_row_load(const float* row, float (&v)[HP]) {
+  if constexpr (HP >= 4) {
+#pragma unroll
+    for (int h = 0; h < HP; h += 4) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(row + h);
+      v[h] = q.x; v[h + 1] = q.y; v[h + 2] = q.z; v[h + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < HP; ++h) v[h] = row[h];
+  }
+}
+
 // Fixed-order reduction over the workgroup of HP per-thread values: wave, then waves in index order.
 template <int HP, bool MAX>
 __device__ __forceinline__ void xa_block_reduce(float (&v)[HP], float (*red)[HP], float* stat) {
@@ -436,6 +463,7 @@ softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H, float* __restrict__ zero
   float (*wred)[HP] = reinterpret_cast<float (*)[HP]>(small);  // [waves][HP] of the block reductions
   float* stat = small + (XA_THREADS / 64) * HP;     // [2][HP]
   const float* sb = M.s + (size_t)b * N * H;
+  XA_STAMP(0);
   XaRaw<BF16> first[XA_WS_U];  // the first rows travel while the softmax is computed
   xa_ws_fetch<BF16>(M.seq, b, N, D, tid / XA_LPR, first);
   float m[HP], zz[HP];
@@ -453,35 +481,50 @@ softmax_wsum_multi_kernel(XaFwdMods mods, int D, int H, float* __restrict__ zero
     for (int r = 0; r < 4; ++r) {
       const int n = n0 + r * XA_THREADS;
       if (n < N) {
+        float v[HP];
 #pragma unroll
         for (int h = 0; h < HP; ++h) {
-          const float v = h < H ? sv[r][h] : 0.f;
-          cs[n * CP + h] = v;
-          if (h < H) m[h] = fmaxf(m[h], v);
+          v[h] = h < H ? sv[r][h] : 0.f;
+          if (h < H) m[h] = fmaxf(m[h], v[h]);
         }
+        xa_row_store<HP>(cs + n * CP, v);
       }
     }
   }
+  XA_STAMP(4);
   xa_block_reduce<HP, true>(m, wred, stat);
+  XA_STAMP(5);
 #pragma unroll
   for (int h = 0; h < HP; ++h) m[h] = stat[h];
   __syncthreads();  // stat is rewritten below
-  for (int n = tid; n < N; n += XA_THREADS)
+  for (int n = tid; n < N; n += XA_THREADS) {  // the exponentials are kept: the second pass only divides
+    float v[HP];
+    xa_row_load<HP>(cs + n * CP, v);
 #pragma unroll
-    for (int h = 0; h < HP; ++h)
-      if (h < H) zz[h] += expf(cs[n * CP + h] - m[h]);
+    for (int h = 0; h < HP; ++h) {
+      v[h] = h < H ? expf(v[h] - m[h]) : 0.f;
+      if (h < H) zz[h] += v[h];
+    }
+    xa_row_store<HP>(cs + n * CP, v);
+  }
   xa_block_reduce<HP, false>(zz, wred, stat + HP);
   float* pb = M.p + (size_t)b * H * N;
-  for (int n = tid; n < N; n += XA_THREADS)
+  for (int n = tid; n < N; n += XA_THREADS) {
+    float v[HP];
+    xa_row_load<HP>(cs + n * CP, v);
 #pragma unroll
     for (int h = 0; h < HP; ++h)
       if (h < H) {
-        const float pv = expf(cs[n * CP + h] - m[h]) / stat[HP + h];
-        cs[n * CP + h] = pv;
-        if (blockIdx.x == 0) pb[(size_t)h * N + n] = pv;
+        v[h] = v[h] / stat[HP + h];
+        if (blockIdx.x == 0) pb[(size_t)h * N + n] = v[h];
       }
+    xa_row_store<HP>(cs + n * CP, v);
+  }
   __syncthreads();
+  XA_STAMP(1);
+  XA_STAMP(2);
   xa_weighted_sum<BF16, HP, CP>(M.seq, cs, red, b, N, D, H, M.z, first);
+  XA_STAMP(3);
 }
 
 template <bool BF16, int HP, bool NEED_U, bool NEED_SEQ>
@@ -525,23 +568,29 @@ token_bwd_multi_kernel(XaBwdMods mods, int D, int H) {
     for (int r = 0; r < 4; ++r) {
       const int n = n0 + r * XA_THREADS;
       if (n < N) {
+        float p_[HP], d_[HP];
 #pragma unroll
         for (int h = 0; h < HP; ++h) {
-          const float p_ = h < H ? pv[r][h] : 0.f, d_ = h < H ? dv[r][h] : 0.f;
-          cs[n * CP + HP + h] = p_;
-          cs[n * CP + h] = d_;
-          if (h < H) acc[h] = fmaf(p_, d_, acc[h]);
+          p_[h] = h < H ? pv[r][h] : 0.f;
+          d_[h] = h < H ? dv[r][h] : 0.f;
+          if (h < H) acc[h] = fmaf(p_[h], d_[h], acc[h]);
         }
+        xa_row_store<HP>(cs + n * CP + HP, p_);
+        xa_row_store<HP>(cs + n * CP, d_);
       }
     }
   }
   XA_STAMP(4);
   xa_block_reduce<HP, false>(acc, wred, stat);
   XA_STAMP(5);
-  for (int n = tid; n < N; n += XA_THREADS)
+  for (int n = tid; n < N; n += XA_THREADS) {
+    float p_[HP], d_[HP];
+    xa_row_load<HP>(cs + n * CP + HP, p_);
+    xa_row_load<HP>(cs + n * CP, d_);
 #pragma unroll
-    for (int h = 0; h < HP; ++h)
-      if (h < H) cs[n * CP + h] = cs[n * CP + HP + h] * (cs[n * CP + h] - stat[h]);
+    for (int h = 0; h < HP; ++h) d_[h] = h < H ? p_[h] * (d_[h] - stat[h]) : 0.f;
+    xa_row_store<HP>(cs + n * CP, d_);
+  }
   __syncthreads();
   XA_STAMP(1);
   if constexpr (NEED_SEQ) {
