@@ -442,6 +442,11 @@ static int launch_scores_mfma(const ScoreMods& mods, int n, int B, int Nmax, int
   int tokb = 64;
   if ((long)B * ((Nmax + 127) / 128) >= 512) tokb = 128;
   if ((long)B * ((Nmax + 255) / 256) >= 1024) tokb = 256;
+  // Once blocks of up to 320 tokens still give every CU a workgroup, a sample is cut into EQUAL blocks of that
+  // size class: a wave then streams five tiles behind one staging of u, and no block is a sliver (N = 577 at
+  // batch 128: 2 x 320 takes 18.3 us where 5 x 128 -- the last one 65 tokens -- takes 23.9 us).
+  const int blocks320 = (Nmax + 319) / 320;
+  if ((long)B * blocks320 >= 256) tokb = ((Nmax + blocks320 - 1) / blocks320 + 63) / 64 * 64;
   if (forced_tokb >= 64 && forced_tokb % 64 == 0) tokb = forced_tokb;
   const dim3 grid((Nmax + tokb - 1) / tokb, B, n), block(SC_THREADS);
 #define VQAF_HSM(S) hipLaunchKernelGGL(head_scores_mfma_kernel<S>, grid, block, 0, st, mods, H, tokb)
