@@ -537,26 +537,20 @@ fold_query_bf16_kernel(FoldSets sets, int B, int H, unsigned long long* count_st
       const u32x2 b_lo = fq_read_tr(rd), b_hi = fq_read_tr(rd + 4 * FQ_WP);
       const fq_frag fb = fq_as_frag(u32x4{b_lo.x, b_lo.y, b_hi.x, b_hi.y});
 #pragma unroll
+      // The two operands of this MFMA have the same register layout (row or column = lane & 15, k = 8 (lane >> 4)
+      // + e), so passing them in the other order yields the TRANSPOSED tile with the same sums: a lane ends with
+      // four consecutive output columns (4 g + r) of ONE query (lane & 15), which leave as one 16-byte store
+      // instead of four 4-byte ones (the 33 MB of u were this kernel's 147 k store instructions).
       for (int p = 2; p >= 0; --p) {  // smallest term first
-        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p][0][s], fb, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p][1][s], fb, o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, af[p][0][s], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, af[p][1][s], o1, 0, 0, 0);
       }
     }
-    float* ur = u + ((size_t)(r0 + 4 * g) * H + h) * D + colbase + li;
-    if (whole) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        ur[(size_t)r * H * D] = o0[r] * scale;
-        ur[(size_t)(r + 16) * H * D] = o1[r] * scale;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + 4 * g + r;
-        if (row < B) ur[(size_t)r * H * D] = o0[r] * scale;
-        if (row + 16 < B) ur[(size_t)(r + 16) * H * D] = o1[r] * scale;
-      }
-    }
+    float* ur = u + ((size_t)(r0 + li) * H + h) * D + colbase + 4 * g;
+    const f32x4 v0 = {o0[0] * scale, o0[1] * scale, o0[2] * scale, o0[3] * scale};
+    const f32x4 v1 = {o1[0] * scale, o1[1] * scale, o1[2] * scale, o1[3] * scale};
+    if (whole || r0 + li < B) *reinterpret_cast<f32x4*>(ur) = v0;
+    if (whole || r0 + 16 + li < B) *reinterpret_cast<f32x4*>(ur + (size_t)16 * H * D) = v1;
   }
 }
 
@@ -705,7 +699,8 @@ static int fold_query_multi(const vqaf_fold_desc* descs_host, int n, int B, int 
   bool fast = fold_bf16_applies(D, H, dtype, w_dtype);
   for (int i = 0; i < n && fast; ++i)  // 16-byte fragment loads
     fast = reinterpret_cast<uintptr_t>(descs_host[i].q) % 16 == 0 &&
-           reinterpret_cast<uintptr_t>(descs_host[i].in_proj_weight) % 16 == 0;
+           reinterpret_cast<uintptr_t>(descs_host[i].in_proj_weight) % 16 == 0 &&
+           reinterpret_cast<uintptr_t>(descs_host[i].u) % 16 == 0;  // 16-byte stores of u
   if (fast) {
     FoldSets fs = {};
     for (int i = 0; i < n; ++i) {
