@@ -245,7 +245,9 @@ def _ones(dev):
     one more problem of a grouped product launch."""
     t = _ONES.get(dev)
     if t is None:
-        t = _ONES[dev] = torch.ones(4, dtype=torch.float32, device=dev)
+        t = torch.ones(4, dtype=torch.float32, device=dev)
+        if not torch.cuda.is_current_stream_capturing():  # (a tensor made during a capture lives in that graph's pool)
+            _ONES[dev] = t
     return t
 
 
