@@ -373,3 +373,67 @@ def test_roberta_stack_matches_oracle_with_padding():
         h, pooled = m.to(DEV)(ids.to(DEV), mask.to(DEV))
     live = mask.bool()
     assert _rel(h[live.to(DEV)], rh[live]) < 1e-2 and _rel(pooled, rp) < 1e-2
+
+
+@pytest.mark.parametrize("wrapper,targets", [("BertQLoRA", None), ("RoBertaQLoRA", ["query", "key", "value"])])
+def test_lora_text_encoders_match_the_oracle_on_merged_weights(wrapper, targets):
+    """BertQLoRA / RoBertaQLoRA (model/text_encoder.py:91-169; the peft package is absent, so parity with it is
+    unpinned): with dropout off the adapted stack computes what the plain stack computes on W + (alpha / r) B A,
+    which the oracle evaluates in float64 as a function of A and B; only adapters and projections train."""
+    torch.manual_seed(3)
+    roberta = wrapper == "RoBertaQLoRA"
+    cfg = (encoders.roberta_config if roberta else encoders.BertConfig)(
+        hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=101,
+        max_position_embeddings=40, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = getattr(encoders, wrapper)(hidden_dim=64, lora_r=8, lora_alpha=16, lora_dropout=0.0, target_modules=targets,
+                                   config=cfg)
+    with torch.no_grad():
+        for p in m.bert.parameters():
+            p.copy_(torch.randn_like(p) * 0.08)   # (the adapters' B matrices too: zeros would hide them)
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
+    assert all(".lora." in n or n.startswith(("seq_projection", "global_projection")) for n in trainable)
+    tset = targets or ["query", "value"]
+    assert sum(".lora_A." in n for n in trainable) == 2 * len(tset)
+    stack = m.bert
+    sd64 = {k: v.detach().double() for k, v in stack.state_dict().items() if ".lora." not in k}
+    ab = {}
+    for i, lyr in enumerate(stack.encoder.layer):
+        for t in lyr.lora.targets:
+            pair = lyr.lora.adapters[t]
+            a = pair.lora_A.weight.detach().double().requires_grad_()
+            b = pair.lora_B.weight.detach().double().requires_grad_()
+            ab[(i, t)] = (a, b)
+            key = f"encoder.layer.{i}.attention.self.{t}.weight"
+            sd64[key] = sd64[key] + lyr.lora.scaling * b @ a
+    # the helper that exports merged weights agrees with that formula
+    merged = encoders.merged_lora_weights(stack)
+    for k, w in merged.items():
+        assert _rel(w, sd64[k]) < 1e-6
+    m.to(DEV).train()
+    ids = torch.randint(2, 101, (4, 30))
+    mask = torch.ones(4, 30, dtype=torch.long)
+    mask[1, 20:] = 0
+    if roberta:
+        ids[1, 20:] = 1
+    h, pooled = stack(ids.to(DEV), mask.to(DEV))
+    rh, rp = eo.bert_forward(sd64, ids, mask, heads=2, eps=cfg.layer_norm_eps, roberta_pad=1 if roberta else None)
+    live = mask.bool()
+    assert _rel(h[live.to(DEV)], rh[live]) < 1e-2 and _rel(pooled, rp) < 1e-2
+    cot = torch.randn(rh.shape, generator=torch.Generator().manual_seed(2)).double() * live[..., None]
+    ((rh * cot).sum() + rp.sum()).backward()
+    ((h.double() * cot.to(DEV)).sum() + pooled.double().sum()).backward()
+    for i, lyr in enumerate(stack.encoder.layer):
+        for t in lyr.lora.targets:
+            pair = lyr.lora.adapters[t]
+            a, b = ab[(i, t)]
+            tol = 8e-2 if t in ("query", "key") else 3e-2
+            assert _rel(pair.lora_A.weight.grad, a.grad) < tol, (i, t, "A", _rel(pair.lora_A.weight.grad, a.grad))
+            assert _rel(pair.lora_B.weight.grad, b.grad) < tol, (i, t, "B", _rel(pair.lora_B.weight.grad, b.grad))
+    assert all(p.grad is None for n, p in stack.named_parameters() if ".lora." not in n)
+    # the wrapper's contract and a step of dropout-on training (masks drawn, shapes kept)
+    q_seq, q_global = m(ids.to(DEV), mask.to(DEV))
+    assert q_seq.shape == (4, 30, 64) and q_global.shape == (4, 64)
+    for lyr in stack.encoder.layer:
+        lyr.lora.p = 0.1
+    q2, _ = m(ids.to(DEV), mask.to(DEV))
+    assert torch.isfinite(q2.float()).all() and not torch.equal(q2, q_seq)

@@ -19,6 +19,7 @@ Activations are bf16 (the attention kernel is bf16 on MFMA with f32 accumulation
 from __future__ import annotations
 
 import json
+import math
 import os
 from dataclasses import dataclass
 
@@ -574,6 +575,47 @@ class _BertAttention(nn.Module):
         self.output = _BertSelfOutput(E, E, eps)
 
 
+class _LoraPair(nn.Module):
+    """One LoRA adapter of a Linear (in -> out): lora_A (r, in), lora_B (out, r), as the PEFT package names and
+    initialises them (A: Kaiming-uniform with a = sqrt(5), B: zeros, so the adapted layer starts as the base one)."""
+
+    def __init__(self, in_f: int, out_f: int, r: int):
+        super().__init__()
+        self.lora_A = nn.Linear(in_f, r, bias=False)
+        self.lora_B = nn.Linear(r, out_f, bias=False)
+        nn.init.kaiming_uniform_(self.lora_A.weight, a=math.sqrt(5))
+        nn.init.zeros_(self.lora_B.weight)
+
+
+class _QkvLora(nn.Module):
+    """LoRA adapters on the query / key / value projections of one attention block (model/text_encoder.py:91-169
+    configures r = 8, alpha = 16, dropout 0.1 on ["query", "value"]):
+        y_t = x W_t^T + b_t + (alpha / r) * dropout(x) A_t^T B_t^T      for every adapted projection t.
+    The adapters of a block share two small products on the packed (3E-wide) output: dropout(x) against the
+    stacked A matrices, then against a (3E, n r) matrix that holds each scaled B in its projection's rows and
+    zeros elsewhere."""
+    ORDER = ("query", "key", "value")
+
+    def __init__(self, E: int, r: int, alpha: float, dropout: float, targets):
+        super().__init__()
+        bad = [t for t in targets if t not in self.ORDER]
+        if bad:
+            raise NotImplementedError(f"LoRA target modules {bad}: only query / key / value are adapted here")
+        self.targets = [t for t in self.ORDER if t in targets]
+        self.adapters = nn.ModuleDict({t: _LoraPair(E, E, r) for t in self.targets})
+        self.E, self.r, self.scaling, self.p = E, r, float(alpha) / r, float(dropout)
+
+    def forward(self, x, training: bool):
+        E, r = self.E, self.r
+        xd = F.dropout(x, self.p, training) if self.p > 0 else x
+        a_cat = torch.cat([self.adapters[t].lora_A.weight for t in self.targets], 0).to(x.dtype)   # (n r, E)
+        b_cat = x.new_zeros(3 * E, len(self.targets) * r)
+        for j, t in enumerate(self.targets):
+            o = self.ORDER.index(t) * E
+            b_cat[o:o + E, j * r:(j + 1) * r] = self.adapters[t].lora_B.weight.to(x.dtype) * self.scaling
+        return _affine(_affine(xd, a_cat, None), b_cat, None)
+
+
 class _BertLayer(nn.Module):
     def __init__(self, cfg: BertConfig):
         super().__init__()
@@ -583,10 +625,14 @@ class _BertLayer(nn.Module):
         self.output = _BertSelfOutput(cfg.intermediate_size, E, cfg.layer_norm_eps)
         self.heads, self.eps, self.p = cfg.num_attention_heads, cfg.layer_norm_eps, cfg.hidden_dropout_prob
         self.p_attn = cfg.attention_probs_dropout_prob
+        self.lora = None  # a _QkvLora once add_lora() has adapted the block
 
     def forward(self, x, key_bias, rng=None):
         a = self.attention.self
-        ctx = self_attention(_packed_qkv(x, a.query, a.key, a.value), key_bias, self.heads,
+        qkv = _packed_qkv(x, a.query, a.key, a.value)
+        if self.lora is not None:
+            qkv = qkv + self.lora(x, self.training)
+        ctx = self_attention(qkv, key_bias, self.heads,
                              self.p_attn if self.training else 0.0, rng)
         att = F.dropout(_linear(ctx, self.attention.output.dense), self.p, self.training)
         ln = self.attention.output.LayerNorm
@@ -725,3 +771,51 @@ class RoBerta(Bert):
         if config is None and not (model_name is not None and os.path.exists(os.path.join(model_name, "config.json"))):
             config = roberta_config()
         super().__init__(model_name, hidden_dim, config, compute_dtype)
+
+
+def add_lora(stack: "BertModel", r: int = 8, alpha: float = 16, dropout: float = 0.1, target_modules=None) -> None:
+    """Freezes every parameter of `stack` and adapts the attention projections named in `target_modules`
+    (default ["query", "value"]) of every block with trainable LoRA pairs: what
+    `get_peft_model(base, LoraConfig(r, lora_alpha, target_modules, lora_dropout, bias="none"))` sets up."""
+    targets = list(target_modules or ["query", "value"])
+    for p in stack.parameters():
+        p.requires_grad_(False)
+    for lyr in stack.encoder.layer:
+        lyr.lora = _QkvLora(stack.config.hidden_size, r, alpha, dropout, targets)
+
+
+def merged_lora_weights(stack: "BertModel") -> dict:
+    """{parameter name: W + (alpha / r) B A} for every adapted projection: the plain weights an adapter-free stack
+    needs to compute the same function (dropout off)."""
+    out = {}
+    for i, lyr in enumerate(stack.encoder.layer):
+        if lyr.lora is None:
+            continue
+        for t in lyr.lora.targets:
+            pair, lin = lyr.lora.adapters[t], getattr(lyr.attention.self, t)
+            out[f"encoder.layer.{i}.attention.self.{t}.weight"] = (
+                lin.weight.detach().float() + lyr.lora.scaling * pair.lora_B.weight.detach().float()
+                @ pair.lora_A.weight.detach().float()).to(lin.weight.dtype)
+    return out
+
+
+class BertQLoRA(Bert):
+    """The reference's `BertQLoRA` wrapper (model/text_encoder.py:91-129): the `Bert` contract on a frozen stack
+    with LoRA adapters (r = 8, alpha = 16, dropout 0.1 on query and value by default); only the adapters and the
+    two projections train.  The adapters are this module's own (the `peft` package is not involved)."""
+
+    def __init__(self, model_name: str | None = None, hidden_dim: int = 512, lora_r: int = 8, lora_alpha: float = 16,
+                 lora_dropout: float = 0.1, target_modules=None, config: BertConfig | None = None,
+                 compute_dtype=torch.bfloat16):
+        super().__init__(model_name, hidden_dim, config, compute_dtype)
+        add_lora(self.bert, lora_r, lora_alpha, lora_dropout, target_modules)
+
+
+class RoBertaQLoRA(RoBerta):
+    """The reference's `RoBertaQLoRA` wrapper (model/text_encoder.py:132-169), as BertQLoRA on the RoBERTa stack."""
+
+    def __init__(self, model_name: str | None = None, hidden_dim: int = 512, lora_r: int = 8, lora_alpha: float = 16,
+                 lora_dropout: float = 0.1, target_modules=None, config: BertConfig | None = None,
+                 compute_dtype=torch.bfloat16):
+        super().__init__(model_name, hidden_dim, config, compute_dtype)
+        add_lora(self.bert, lora_r, lora_alpha, lora_dropout, target_modules)
