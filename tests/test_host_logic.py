@@ -211,3 +211,33 @@ def test_loops_run_on_cpu_with_concat_fusion():
     m2 = VQAModel(vision=V, text=T, fusion_type="concat", hidden_dim=32, num_classes=5)
     load_weights(m2, sd)
     assert torch.equal(m2.classifier[0].weight, m.classifier[0].weight)
+
+
+def test_lora_text_encoder_wrappers_have_the_reference_surface():
+    """BertQLoRA / RoBertaQLoRA (model/text_encoder.py:91-169): constructor argument names, attribute names and
+    what trains (adapters + the two projections; the stack itself is frozen)."""
+    import inspect
+    from vqa_amd import encoders
+    small = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=128, vocab_size=50,
+                 max_position_embeddings=16)
+    for cls, cfg in ((encoders.BertQLoRA, encoders.BertConfig(**small)),
+                     (encoders.RoBertaQLoRA, encoders.roberta_config(**small))):
+        names = list(inspect.signature(cls.__init__).parameters)
+        assert names[1:7] == ["model_name", "hidden_dim", "lora_r", "lora_alpha", "lora_dropout", "target_modules"]
+        m = cls(hidden_dim=32, lora_r=4, lora_alpha=8, config=cfg)
+        assert hasattr(m, "bert") and m.output_dim == 32
+        assert m.seq_projection.out_features == 32 and m.global_projection.out_features == 32
+        train = [n for n, p in m.named_parameters() if p.requires_grad]
+        assert train and all(".lora_" in n or n.split(".")[0] in ("seq_projection", "global_projection") for n in train)
+        assert sum(".lora_A." in n for n in train) == 2 * 2  # query and value of two blocks
+        a = m.bert.encoder.layer[0].lora.adapters["query"]
+        assert a.lora_A.weight.shape == (4, 64) and a.lora_B.weight.shape == (64, 4)
+        assert float(a.lora_B.weight.abs().max()) == 0.0 and m.bert.encoder.layer[0].lora.scaling == 2.0
+        merged = encoders.merged_lora_weights(m.bert)  # B = 0: the merged weights are the base weights
+        k = "encoder.layer.0.attention.self.query.weight"
+        assert k in merged and bool((merged[k] == m.bert.encoder.layer[0].attention.self.query.weight).all())
+    try:
+        encoders.BertQLoRA(config=encoders.BertConfig(**small), target_modules=["dense"])
+        raise AssertionError("an unsupported target module must be refused")
+    except NotImplementedError:
+        pass
