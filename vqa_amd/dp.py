@@ -663,9 +663,11 @@ class DPOptimizer:
             b1, b2 = group["betas"]
             nz = noise[lo:hi] if noise is not None else None
             noise_state = self._step if single else self._rng.state
+            # (in a process group the kernel reads the reduced gradient bucket itself: nothing to write back)
             check(lib.vqaf_dp_adamw(ptr(src[lo:hi]), ptr(nz), ptr(noise_state), std, scale,
                                     ptr(self._P[lo:hi]), ptr(self._M[lo:hi]), ptr(self._V[lo:hi]),
-                                    ptr(self._shadow[lo:hi]), ptr(grad[lo:hi]), hi - lo, float(group["lr"]),
+                                    ptr(self._shadow[lo:hi]), ptr(grad[lo:hi]) if world == 1 else None, hi - lo,
+                                    float(group["lr"]),
                                     float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                                     ptr(self._step), -1 if counted else 0, st), "vqaf_dp_adamw")
             if world == 1 and nz is None and std != 0.0 and not single:
