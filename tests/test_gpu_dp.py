@@ -866,3 +866,32 @@ def test_update_fused_into_the_clipped_sums_equals_the_separate_launches(dev):
             for o, n in spans:
                 assert torch.equal(a[o:o + n], b[o:o + n])
         assert float(runs[0][0].abs().sum()) > 0 and float(runs[0][3].abs().sum()) > 0
+
+
+def test_f32_to_bf16_rounding_is_torch_s(dev):
+    """Every f32 -> bf16 rounding in the library is one hardware conversion (v_cvt_pk_bf16_f32).  Through
+    vqaf_scale_cast (packed pairs, and single values in its tail) it must equal torch's rounding bit for bit on
+    ties, subnormals, infinities, the largest finite values and random data, and keep NaN a NaN."""
+    import struct
+    from vqa_amd._lib import BF16, check, load, ptr, stream_ptr
+    lib, st = load(), stream_ptr(dev)
+
+    def f(bits):
+        return struct.unpack("<f", struct.pack("<I", bits))[0]
+
+    special = [0.0, -0.0, 1.0, -1.0, f(0x3F808000), f(0x3F818000), f(0x3F807FFF), f(0x3F808001),  # ties to even
+               f(0x00000001), f(0x00008000), f(0x00018000), f(0x007FFFFF), f(0x80010000),          # subnormals
+               f(0x7F7FFFFF), f(0x7F7F7FFF), f(0x7F7F8000), float("inf"), float("-inf"), 65504.0, 1e-40, 3.0e38]
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.cat([torch.tensor(special, device=dev),
+                   torch.randn(100003, device=dev, generator=gen) * 10.0 ** torch.randint(-30, 30, (100003,), device=dev,
+                                                                                       generator=gen).float()])
+    one = torch.ones(1, device=dev)
+    out = torch.empty(x.numel(), dtype=torch.bfloat16, device=dev)
+    check(lib.vqaf_scale_cast(ptr(x), ptr(one), x.numel(), BF16, ptr(out), st), "vqaf_scale_cast")
+    want = x.to(torch.bfloat16)
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+    nan = torch.tensor([float("nan"), -float("nan"), f(0x7F800001), f(0xFFC12345), 1.0, 2.0, 3.0, 4.0, 5.0], device=dev)
+    outn = torch.empty(nan.numel(), dtype=torch.bfloat16, device=dev)
+    check(lib.vqaf_scale_cast(ptr(nan), ptr(one), nan.numel(), BF16, ptr(outn), st), "vqaf_scale_cast")
+    assert bool(torch.isnan(outn[:4].float()).all()) and outn[4:].float().tolist() == [1.0, 2.0, 3.0, 4.0, 5.0]
