@@ -335,6 +335,59 @@ def dense_leg(dev, dtype):
     return out
 
 
+def mia_leg(dev, dtype):
+    """BASELINE configs[4] at one GPU's share of an 8-GPU run: the membership-inference scoring pass
+    (attack/metric_src.py:318-426: per-sample loss and confidence in eval mode) over 25 000 token-level samples
+    (200 000 / 8) in batches of 1000 -- fusion forward (pruning keep 0.5), classifier forward, one fused
+    loss + confidence launch per batch -- and that launch alone over a shard's 25 000 x 430 logits."""
+    from vqa_amd import dp, fusion, mia, ops
+    torch.manual_seed(42)
+    fus = fusion.CoAttention(embed_dim=D, num_heads=8, use_pruning=True, prune_ratio=1 - KEEP, noise_injection=False).to(dev)
+    cls = nn.Sequential(nn.Linear(2 * D, 2048), nn.BatchNorm1d(2048), nn.ReLU(), nn.Dropout(0.3),
+                        nn.Linear(2048, 1024), nn.BatchNorm1d(1024), nn.ReLU(), nn.Linear(1024, C))
+    cls = dp.ModuleValidator.fix(cls).to(dev)
+    if dtype == torch.bfloat16:
+        fus, cls = fus.to(dtype), cls.to(dtype)
+    fus.eval()
+    cls.eval()
+    shard, bs = 25000, 1000
+    gen = torch.Generator(device=dev).manual_seed(7)
+    v = torch.randn(bs, N_VIS, D, device=dev, generator=gen).to(dtype)
+    q = torch.randn(bs, N_TXT, D, device=dev, generator=gen).to(dtype)
+    vg, qg = v.float().mean(1).to(dtype), q.float().mean(1).to(dtype)
+    y = torch.randint(0, C, (bs,), device=dev, generator=gen)
+
+    def batch():
+        with torch.no_grad():
+            logits = cls(fus(v, vg, q, qg))
+            loss, conf, _ = mia.score_logits(logits, y)
+        return loss, conf
+
+    for _ in range(3):
+        batch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(shard // bs):
+        batch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    logits = torch.randn(shard, C, device=dev, generator=gen).to(dtype)
+    yy = torch.randint(0, C, (shard,), device=dev, generator=gen)
+    for _ in range(3):
+        mia.score_logits(logits, yy)
+    e0.record()
+    for _ in range(10):
+        mia.score_logits(logits, yy)
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / 10
+    nbytes = shard * (C * logits.element_size() + 8 + 4 + 4 + 8)
+    return {"workload": "configs[4], one GPU's shard of 8: 25 000 samples, batches of 1000, eager launches",
+            "ms": round(ms, 3), "samples/s": round(shard / ms * 1e3, 1),
+            "ce_conf_kernel_ms_25000x430": round(k_ms, 5), "ce_conf_GB/s": round(nbytes / k_ms / 1e6, 1)}
+
+
 def transformers_encoders_ms(dev, vqa_model, imgs, ids, mask, y):
     """The same model and step with the two encoder stacks taken from the `transformers` package (what
     model/vision_encoder.py:97 and model/text_encoder.py:21 construct), eager launches, same GPU: the
@@ -725,6 +778,7 @@ def main():
         if not args.no_sweep:
             line["prune_mix_cfg4"] = prune_mix_sweep(dev, dtype)
             line["dense_branch"] = dense_leg(dev, dtype)
+            line["mia_cfg5"] = mia_leg(dev, dtype)
             if dtype == torch.bfloat16:
                 line["one_pass_kernel"] = one_pass_leg(dev)
         if not args.no_full_model and dtype == torch.bfloat16 and world == 1:  # a one-GPU measurement
