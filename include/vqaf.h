@@ -407,7 +407,8 @@ int vqaf_gemm_f32_atomic_sets(int n_sets, const void* const* A_host, int a_dtype
  * products that do not depend on each other -- in the backward of the attention modules
  * (utils/fusion.py:194-200, 257-268 under autograd) the input gradient through the value projection and two
  * weight gradients all follow from one incoming gradient -- and would otherwise each occupy the stream for
- * a launch of their own. */
+ * a launch of their own.  With store = 1 it is also the f32 tier's clipped sums of the DP step (Opacus
+ * clip_and_accumulate behind utils/src.py:104): S_W = G^T A and S_b = 1^T G of every Linear in one launch. */
 typedef struct vqaf_gemm_desc {
   const void* A;    /* element (g, m, k) at A + g*a_sg + m*a_sm + k*a_sk (elements of a_dtype) */
   const void* Bm;   /* element (g, k, n) at Bm + g*b_sg + k*b_sk + n*b_sn */
@@ -417,6 +418,8 @@ typedef struct vqaf_gemm_desc {
   int a_dtype, b_dtype, bias_dtype;
   int G, M, N, K;
   float alpha;
+  int store;        /* 0: C += result (C zero-filled by the caller; long contractions may be split, f32 atomics);
+                       1: C = result, plain stores, the contraction is never split (deterministic) */
 } vqaf_gemm_desc;
 int vqaf_gemm_f32_group(int n, const vqaf_gemm_desc* probs_host, vqaf_stream_t stream);
 

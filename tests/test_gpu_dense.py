@@ -228,15 +228,17 @@ def test_fused_token_kernels_are_bit_identical_to_the_separate_launches(dev, dty
     ones = torch.ones(4, **f32)
     x4 = torch.randn(700, 200, device=dev, generator=gen).to(dtype)
     c1, c2, c3, c4 = (torch.zeros(*sh, **f32) for sh in ((70, 130), (48, 96), (4, 33, 40), (200,)))
+    c2.fill_(7.0)  # problems 2 and 4 are STORED: what their outputs held before does not matter
+    c4.fill_(-3.0)
     descs = (_lib.GemmDesc * 4)(
         _lib.GemmDesc(ptr(a1), ptr(b1), ptr(bias1), ptr(c1), 0, 300, 1, 0, 130, 1, 0, 0, 130,
-                      dtype_code(a1), _lib.F32, _lib.F32, 1, 70, 130, 300, 0.5),
+                      dtype_code(a1), _lib.F32, _lib.F32, 1, 70, 130, 300, 0.5, 0),
         _lib.GemmDesc(ptr(a2), ptr(b2), None, ptr(c2), 0, 1, 48, 0, 96, 1, 0, 0, 96,
-                      _lib.F32, dtype_code(b2), _lib.F32, 1, 48, 96, 256, 1.0),
+                      _lib.F32, dtype_code(b2), _lib.F32, 1, 48, 96, 256, 1.0, 1),
         _lib.GemmDesc(ptr(a3), ptr(b3), None, ptr(c3), 33 * 64, 64, 1, 64 * 40, 40, 1, 0, 33 * 40, 40,
-                      _lib.F32, _lib.F32, _lib.F32, 4, 33, 40, 64, 2.0),
+                      _lib.F32, _lib.F32, _lib.F32, 4, 33, 40, 64, 2.0, 0),
         _lib.GemmDesc(ptr(ones), ptr(x4), None, ptr(c4), 0, 0, 0, 0, 200, 1, 0, 0, 200,
-                      _lib.F32, dtype_code(x4), _lib.F32, 1, 1, 200, 700, 1.0))
+                      _lib.F32, dtype_code(x4), _lib.F32, 1, 1, 200, 700, 1.0, 1))
     check(lib.vqaf_gemm_f32_group(4, ctypes.cast(descs, ctypes.c_void_p), st), "gemm group")
     want = (0.5 * a1.double() @ b1.double() + bias1.double(), a2.double().t() @ b2.double(),
             2.0 * torch.bmm(a3.double(), b3.double()), x4.double().sum(0))

@@ -474,11 +474,14 @@ def _unambiguous_rows(cpu_m, x, tol=2e-5):
     return keep
 
 
-def test_dp_step_f32_batch_256_vs_chunked_oracle(dev):
+@pytest.mark.parametrize("library_sums", [True, False])
+def test_dp_step_f32_batch_256_vs_chunked_oracle(dev, library_sums, monkeypatch):
     """One whole DP step of the BASELINE classifier at B = 256 (4 pipeline stages, split head)
     against the per-sample-gradient oracle evaluated in chunks of 32 samples; the clip norm is the
-    median per-sample norm, so both branches of the clip are taken."""
+    median per-sample norm, so both branches of the clip are taken.  The Linear layers' weight sums as
+    library GEMMs + one grouped bias-sum launch, and all of them in the grouped launch."""
     from vqa_amd import dp
+    monkeypatch.setattr(dp, "F32_SUMS_IN_LIBRARY", library_sums)
     in_dim, hidden, C, B, sigma, E = 1024, 1024, 430, 256, 1.0, 1024
     cpu_m = _classifier(500, in_dim, hidden, C)
     x, y = gi.normal(61, B + 64, in_dim), gi.labels(62, B + 64, C)

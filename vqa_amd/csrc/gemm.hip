@@ -283,7 +283,8 @@ int gemm_launch(const GemmSets& sets, int nsets, int a_dtype, long a_sg, long a_
 // brings its own shape, strides, operand types and staging modes, a workgroup finds its problem from the
 // running tile count, and the body is gemm_f32_kernel's with the staging mode chosen at run time (uniform per
 // workgroup).  Outputs are ADDED into C (the caller provides it zero-filled); long contractions are split over
-// workgroups with f32 atomics, as in vqaf_gemm_f32_atomic.
+// workgroups with f32 atomics, as in vqaf_gemm_f32_atomic -- or, per problem, written with plain stores by
+// workgroups that each take a whole contraction (the f32 clipped sums of the DP step: many tiles, nothing to clear).
 constexpr int GEMM_MAX_GROUP = 12;
 struct GemmProb {
   const void* A;
@@ -296,6 +297,7 @@ struct GemmProb {
   int amode, bmode, a_bf16, b_bf16, bias_bf16;
   int splits, k_per_split, tiles_x, tiles_y;
   int wg_begin;  // first workgroup of this problem
+  int store;     // C = result with plain stores (the contraction is then never split); else C += result (atomics)
 };
 struct GemmGroupArgs {
   GemmProb p[GEMM_MAX_GROUP];
@@ -397,7 +399,11 @@ gemm_f32_group_kernel(GemmGroupArgs args) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int gm = gm0 + (r & 3) + 8 * (r >> 2);
-    if (gm < M && gn < N) atomicAdd(c0 + (long)gm * P.c_sm, alpha * acc[r] + bias_v);
+    if (gm < M && gn < N) {
+      const float v = alpha * acc[r] + bias_v;
+      if (P.store) c0[(long)gm * P.c_sm] = v;
+      else atomicAdd(c0 + (long)gm * P.c_sm, v);
+    }
   }
 }
 
@@ -660,9 +666,10 @@ extern "C" int vqaf_gemm_f32_group(int n, const vqaf_gemm_desc* probs_host, vqaf
     // the whole group should fill the chip about once: long contractions are split over workgroups
     const long tiles = (long)P.tiles_x * P.tiles_y * d.G;
     int splits = 1;
-    if (total_tiles < 256 && d.K >= 4 * GK)
+    if (!d.store && total_tiles < 256 && d.K >= 4 * GK)
       while (splits < 16 && total_tiles * splits < 512 && d.K / (splits * 2) >= 2 * GK) splits *= 2;
     P.splits = splits;
+    P.store = d.store != 0;
     P.k_per_split = ((d.K + splits - 1) / splits + GK - 1) / GK * GK;
     P.wg_begin = wg;
     VQAF_REQUIRE(tiles * splits < (1l << 24), VQAF_E_SHAPE);

@@ -36,6 +36,10 @@ from . import ops
 from ._lib import check, dtype_code, load, ptr, stream_ptr
 from .accountant import RDPAccountant, get_noise_multiplier
 
+# fp32 tapes: the Linear layers' clipped weight sums S_W = G^T A run as library GEMMs (True) or as problems of
+# this library's grouped f32 launch (False); see DPOptimizer.clip_and_accumulate.
+F32_SUMS_IN_LIBRARY = True
+
 
 # --------------------------------------------------------------------------------------------
 # ModuleValidator.fix  (train.py:124)
@@ -810,6 +814,33 @@ class DPOptimizer:
                           self._slice(S, t.module.bias) if t.module.bias is not None else None) for t in cand]
                 if ops.gemm_bf16_wgrad_group(items, B, name=probe):
                     grouped = cand
+            # f32 tapes: S_W = G^T A is a plain f32 product of two row-major matrices -- the library GEMM (hipBLASLt
+            # through torch.mm, 128-wide tiles) runs it at about 115 TFLOP/s, the 64 x 64 tiles of this library at
+            # 65-80 -- and every S_b = 1^T G is a problem of ONE grouped launch that writes them with plain stores
+            # (nothing to clear beforehand).  F32_SUMS_IN_LIBRARY = False puts the S_W products into that launch too.
+            f32 = [t for t in tapes if t.kind == "linear" and t.g.dtype == torch.float32 and
+                   t.a.dtype == torch.float32 and t.g.is_contiguous() and t.a.is_contiguous()]
+            if f32 and sum(1 + (t.module.bias is not None) for t in f32) <= 12 and B >= 64:
+                from .xattn import _gemm_group, _ones, _prob
+                one = _ones(dev)
+                probs = []
+                for t in f32:
+                    In_, Out_ = t.a.shape[1], t.g.shape[1]
+                    if not F32_SUMS_IN_LIBRARY:
+                        probs.append(_prob((t.g, 0), (0, 1, Out_), (t.a, 0), (0, In_, 1),
+                                           (self._slice(S, t.module.weight), 0), (0, In_), 1, Out_, In_, B, store=True))
+                    if t.module.bias is not None:
+                        probs.append(_prob((one, 0), (0, 0, 0), (t.g, 0), (0, Out_, 1),
+                                           (self._slice(S, t.module.bias), 0), (0, Out_), 1, 1, Out_, B, store=True))
+                probe = "clipped_sum_linear:" + "+".join(f"{t.g.shape[1]}x{t.a.shape[1]}" for t in f32)
+                ops._probe(probe, "begin")
+                if F32_SUMS_IN_LIBRARY:
+                    for t in f32:
+                        torch.mm(t.g.t(), t.a, out=self._slice(S, t.module.weight).view(t.g.shape[1], t.a.shape[1]))
+                if probs:
+                    _gemm_group(probs)
+                ops._probe(probe, "end")
+                grouped = grouped + f32
         # the affine (GroupNorm) layers' sums share one launch too when their slices are already zeroed
         affine = [t for t in tapes if t.kind != "linear"]
         if pre_zeroed and 2 <= len(affine) <= 8 and all(t.g.dtype == affine[0].g.dtype and t.g.is_contiguous()

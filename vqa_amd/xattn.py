@@ -251,14 +251,15 @@ def _ones(dev):
     return t
 
 
-def _prob(A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha=1.0, bias=None, bias_sg=0):
-    """One problem of _gemm_group: the arguments of _gemm."""
-    return (A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha, bias, bias_sg)
+def _prob(A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha=1.0, bias=None, bias_sg=0, store=False):
+    """One problem of _gemm_group: the arguments of _gemm.  store: C = result (plain stores, contraction not
+    split) instead of C += result."""
+    return (A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha, bias, bias_sg, store)
 
 
 def _gemm_group(probs):
     """Up to 12 different products (see _gemm for the arguments of each) in ONE launch, each added into its
-    zero-filled C: products that do not depend on each other share the launch instead of occupying the
+    zero-filled C (or stored, see _prob): products that do not depend on each other share the launch instead of occupying the
     stream one after the other."""
     def addr(pair):
         t, off = pair
@@ -268,12 +269,12 @@ def _gemm_group(probs):
         return _lib.BF16 if t.dtype == torch.bfloat16 else _lib.F32
 
     arr = (_lib.GemmDesc * len(probs))()
-    for i, (A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha, bias, bias_sg) in enumerate(probs):
+    for i, (A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha, bias, bias_sg, store) in enumerate(probs):
         assert C[0].dtype == torch.float32
         arr[i] = _lib.GemmDesc(addr(A), addr(Bm), addr(bias) if bias is not None else None, addr(C),
                                a_s[0], a_s[1], a_s[2], b_s[0], b_s[1], b_s[2], bias_sg, c_s[0], c_s[1],
                                code(A[0]), code(Bm[0]), code(bias[0]) if bias is not None else _lib.F32,
-                               G, M, N, K, float(alpha))
+                               G, M, N, K, float(alpha), int(store))
     import ctypes
     check(load().vqaf_gemm_f32_group(len(probs), ctypes.cast(arr, ctypes.c_void_p), stream_ptr(probs[0][4][0].device)),
           "vqaf_gemm_f32_group")
