@@ -126,6 +126,17 @@ def main():
     run("head_scores", B * (N * D * s + N * H * 4),
         lambda i: check(lib.vqaf_head_scores(ptr(seqs[i % nbuf]), ptr(u), B, N, D, H, dtype_code(seqs[0]), ptr(sc), st),
                         "x"))
+    qu = torch.randn(B, H, D, device=dev)
+    qsc = torch.empty(B, Nt, H, device=dev)
+    sds = []
+    for i in range(nbuf):
+        sd = (L.ScoresDesc * 2)()
+        sd[0] = L.ScoresDesc(ptr(seqs[i]), ptr(u), ptr(sc), N)
+        sd[1] = L.ScoresDesc(ptr(qseqs[i]), ptr(qu), ptr(qsc), Nt)
+        sds.append(sd)
+    run("head_scores_multi", B * ((N + Nt) * D * s + (N + Nt) * H * 4),
+        lambda i: check(lib.vqaf_head_scores_multi(ctypes.cast(sds[i % nbuf], ctypes.c_void_p), 2, B, D, H,
+                                                   dtype_code(seqs[0]), st), "x"))
     wout = torch.empty(B, N, device=dev)
     run("attn_weights", B * (N * H * 4 + N * 4),
         lambda i: check(lib.vqaf_attn_weights(ptr(sc), B, N, H, ptr(wout), st), "x"))

@@ -746,6 +746,8 @@ class DPOptimizer:
                         prescaled_ and t.a.dtype == torch.bfloat16 and
                         ops.gemm_bf16_supported(t.g.stride(0), True, t.a.shape[1], True, t.g.shape[1], t.a.shape[1], B)):
                     out += [self._slice(S, m.weight)] + ([self._slice(S, m.bias)] if m.bias is not None else [])
+                elif prescaled_ and F32_SUMS_IN_LIBRARY and t.g.dtype == torch.float32 and m.bias is not None:
+                    out += [self._slice(S, m.bias)]  # (column sums of G over the batch, split over workgroups)
             return out
 
         pre_zeroed = False
@@ -816,8 +818,8 @@ class DPOptimizer:
                     grouped = cand
             # f32 tapes: S_W = G^T A is a plain f32 product of two row-major matrices -- the library GEMM (hipBLASLt
             # through torch.mm, 128-wide tiles) runs it at about 115 TFLOP/s, the 64 x 64 tiles of this library at
-            # 65-80 -- and every S_b = 1^T G is a problem of ONE grouped launch that writes them with plain stores
-            # (nothing to clear beforehand).  F32_SUMS_IN_LIBRARY = False puts the S_W products into that launch too.
+            # 65-80 -- and every S_b = 1^T G is a problem of ONE grouped launch.  F32_SUMS_IN_LIBRARY = False puts the
+            # S_W products into that launch too, everything written with plain stores (nothing to clear beforehand).
             f32 = [t for t in tapes if t.kind == "linear" and t.g.dtype == torch.float32 and
                    t.a.dtype == torch.float32 and t.g.is_contiguous() and t.a.is_contiguous()]
             if f32 and sum(1 + (t.module.bias is not None) for t in f32) <= 12 and B >= 64:
@@ -830,8 +832,11 @@ class DPOptimizer:
                         probs.append(_prob((t.g, 0), (0, 1, Out_), (t.a, 0), (0, In_, 1),
                                            (self._slice(S, t.module.weight), 0), (0, In_), 1, Out_, In_, B, store=True))
                     if t.module.bias is not None:
+                        # a 1 x Out product: stored by one workgroup per 64 outputs it would be one long chain of
+                        # fetches, so it is split over the batch and added into its slice (cleared by the clip launch)
                         probs.append(_prob((one, 0), (0, 0, 0), (t.g, 0), (0, Out_, 1),
-                                           (self._slice(S, t.module.bias), 0), (0, Out_), 1, 1, Out_, B, store=True))
+                                           (self._slice(S, t.module.bias), 0), (0, Out_), 1, 1, Out_, B,
+                                           store=not (pre_zeroed and F32_SUMS_IN_LIBRARY)))
                 probe = "clipped_sum_linear:" + "+".join(f"{t.g.shape[1]}x{t.a.shape[1]}" for t in f32)
                 ops._probe(probe, "begin")
                 if F32_SUMS_IN_LIBRARY:
