@@ -186,3 +186,38 @@ def test_mia_scoring_at_config5_shard_size(dev):
     np.testing.assert_allclose(loss.cpu().numpy(), ref_loss.cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(conf.cpu().numpy(), ref_conf.cpu().numpy(), rtol=1e-5, atol=1e-7)
     assert torch.equal(pred, ref_pred)
+
+
+@pytest.mark.parametrize("name,tokens", [("CNN", 64), ("ResNet50", 4), ("SwinTransformer", 49)])
+def test_vision_wrappers_feed_the_fusion_kernels(dev, name, tokens):
+    """The reference's vision encoders (model/vision_encoder.py:8-127; its configurations pair ResNet50 with
+    Bert) in front of CoAttention with pruning: forward + backward of the whole VQAModel on the GPU in bf16,
+    token count and gradients as expected, the pruning kernels fed by the encoder's token layout as it comes
+    (channels-last feature maps are contiguous tokens; the 1x1 projection of ResNet50 is a strided view)."""
+    import functools
+    from vqa_amd import encoders, vision
+    from vqa_amd.model import VQAModel
+    torch.manual_seed(11)
+    vis = vision.get_vision_registry()[name]
+    text = functools.partial(encoders.Bert, config=encoders.BertConfig(
+        hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256, vocab_size=200))
+    model = VQAModel(vision=vis, text=text, fusion_type="co_attention", hidden_dim=64, num_classes=13,
+                     use_token_pruning=True, prune_ratio=0.5).to(dev).to(torch.bfloat16)
+    B = 4
+    side = 224 if name == "SwinTransformer" else 64  # (the default Swin-T configuration takes 224 x 224 pixels)
+    images = torch.randn(B, 3, side, side, device=dev, dtype=torch.bfloat16)
+    ids = torch.randint(0, 200, (B, 12), device=dev)
+    mask = torch.ones(B, 12, dtype=torch.long, device=dev)
+    seen = {}
+
+    def note(module, args):
+        seen["v_seq"] = args[0].shape
+
+    hook = model.fusion_module.register_forward_pre_hook(note)
+    logits = model(images, ids, mask)
+    hook.remove()
+    assert seen["v_seq"] == (B, tokens, 512)
+    assert logits.shape == (B, 13) and torch.isfinite(logits.float()).all()
+    logits.float().logsumexp(1).sum().backward()
+    first = next(model.vision_encoder.parameters())
+    assert first.grad is not None and torch.isfinite(first.grad.float()).all() and float(first.grad.float().abs().sum()) > 0

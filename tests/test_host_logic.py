@@ -241,3 +241,73 @@ def test_lora_text_encoder_wrappers_have_the_reference_surface():
         raise AssertionError("an unsupported target module must be refused")
     except NotImplementedError:
         pass
+
+
+def test_vision_wrappers_have_the_reference_surface(tmp_path):
+    """CNN / ResNet50 / SwinTransformer (model/vision_encoder.py:8-127): registry names, constructor arguments,
+    state-dict keys (so the reference's checkpoints load key for key), the (v_seq, v_global) contract, and -- for
+    the backbone no library provides here -- the published size of ResNet-50 (25,557,032 parameters with its
+    1000-way head of 2,049,000: 23,508,032 without)."""
+    import torch.nn.functional as F
+    from vqa_amd import vision
+    assert list(vision.get_vision_registry()) == ["CNN", "ResNet50", "SwinTransformer"]
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 64, 64)
+
+    cnn = vision.CNN(out_features=512).eval()
+    sd = cnn.state_dict()
+    assert [k for k in sd if not k.endswith("num_batches_tracked")] == [
+        f"layer{i}.{j}.{n}" for i in (1, 2, 3)
+        for j, names in ((0, ("weight", "bias")), (1, ("weight", "bias", "running_mean", "running_var")))
+        for n in names] + ["fc.weight", "fc.bias"]
+    for i in (1, 2, 3):  # running statistics away from their initial values, so that batch norm does something
+        bn = getattr(cnn, f"layer{i}")[1]
+        bn.running_mean.uniform_(-0.5, 0.5)
+        bn.running_var.uniform_(0.5, 2.0)
+    with torch.no_grad():
+        v_seq, v_global = cnn(x)
+        h = x
+        for i in (1, 2, 3):  # the same three stages spelled out with functional ops
+            conv, bn = getattr(cnn, f"layer{i}")[0], getattr(cnn, f"layer{i}")[1]
+            h = F.conv2d(h, conv.weight, conv.bias, padding=1)
+            h = (h - bn.running_mean[None, :, None, None]) / torch.sqrt(bn.running_var[None, :, None, None] + bn.eps)
+            h = F.max_pool2d(torch.relu(h * bn.weight[None, :, None, None] + bn.bias[None, :, None, None]), 2)
+    assert v_seq.shape == (2, 64, 512) and v_global.shape == (2, 512) and cnn.output_dim == 512
+    torch.testing.assert_close(v_seq, h.flatten(2).permute(0, 2, 1), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(v_global, F.linear(h.mean((2, 3)), cnn.fc.weight, cnn.fc.bias), rtol=1e-4, atol=1e-5)
+
+    res = vision.ResNet50(out_features=256).eval()
+    assert sum(p.numel() for p in res.resnet_features.parameters()) == 23_508_032
+    keys = set(res.state_dict())
+    assert {"resnet_features.0.weight", "resnet_features.1.running_var", "resnet_features.4.0.downsample.0.weight",
+            "resnet_features.4.0.downsample.1.bias", "resnet_features.6.5.conv2.weight",
+            "resnet_features.7.2.bn3.weight", "seq_projection.weight", "seq_projection.bias",
+            "global_projection.weight"} <= keys
+    with torch.no_grad():
+        v_seq, v_global = res(x)  # 64 x 64 pixels: a 2 x 2 map (224 x 224: 7 x 7 = 49 tokens)
+    assert v_seq.shape == (2, 4, 256) and v_global.shape == (2, 256) and res.output_dim == 256
+    # a backbone checkpoint under the names of the full network (conv1.*, layer1.0.bn1.*, fc.*) loads into a second model
+    names = vision.ResNet50._CHILDREN
+    full = {names[int(k.split(".", 1)[0])] + "." + k.split(".", 1)[1]: v for k, v in res.resnet_features.state_dict().items()}
+    full["fc.weight"], full["fc.bias"] = torch.zeros(1000, 2048), torch.zeros(1000)
+    path = str(tmp_path / "resnet50.pt")
+    torch.save(full, path)
+    res2 = vision.ResNet50(out_features=256, weights=path).eval()
+    res2.seq_projection.load_state_dict(res.seq_projection.state_dict())
+    res2.global_projection.load_state_dict(res.global_projection.state_dict())
+    with torch.no_grad():
+        v_seq2, v_global2 = res2(x)
+    assert torch.equal(v_seq2, v_seq) and torch.equal(v_global2, v_global)
+
+    from transformers import SwinConfig
+    cfg = SwinConfig(image_size=64, patch_size=4, embed_dim=16, depths=(1, 1), num_heads=(2, 4), window_size=4)
+    swin = vision.SwinTransformer(out_features=128, config=cfg).eval()
+    assert {"swin.embeddings.patch_embeddings.projection.weight", "seq_projection.weight",
+            "global_projection.bias"} <= set(swin.state_dict())
+    with torch.no_grad():
+        v_seq, v_global = swin(x)
+    assert v_seq.shape == (2, 64, 128) and v_global.shape == (2, 128) and swin.output_dim == 128
+    # the default configuration is Swin-T: 49 tokens of width 768 at 224 x 224 pixels
+    d = SwinConfig()
+    assert (d.embed_dim, tuple(d.depths), tuple(d.num_heads), d.window_size, d.hidden_size) == \
+        (96, (2, 2, 6, 2), (3, 6, 12, 24), 7, 768)
