@@ -6,7 +6,8 @@ The reference builds its encoders from Hugging Face models and projects them to 
 `output_dim` and are passed to `VQAModel` as classes called with `out_features=` / `hidden_dim=`.
 
 Here the transformer stacks themselves are built on the HIP kernels of csrc/encoder.hip (attention,
-LayerNorm with the residual add, GELU); the Linear layers are plain library GEMMs.  `ViTModel` is a
+LayerNorm with the residual add, GELU), their Linear layers on the library's own bf16 GEMM kernels (csrc/linear_nt.hip,
+csrc/wgrad256.hip, csrc/gemm_bf16.hip; shapes those do not cover fall to torch's BLAS library).  `ViTModel` is a
 ViT-B/16-shaped stack (pre-LayerNorm blocks, CLS token, tanh pooler) and `BertModel` a BERT-base-shaped
 one (post-LayerNorm blocks, additive padding mask, tanh pooler).  Parameter names and shapes are those of
 the Hugging Face checkpoints of the two architectures (transformers 4.52, the version the reference pins:
