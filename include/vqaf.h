@@ -413,13 +413,15 @@ typedef struct vqaf_gemm_desc {
   const void* A;    /* element (g, m, k) at A + g*a_sg + m*a_sm + k*a_sk (elements of a_dtype) */
   const void* Bm;   /* element (g, k, n) at Bm + g*b_sg + k*b_sk + n*b_sn */
   const void* bias; /* element (g, n) at bias + g*bias_sg + n, or NULL */
-  float* C;         /* element (g, m, n) at C + g*c_sg + m*c_sm + n */
+  void* C;          /* element (g, m, n) at C + g*c_sg + m*c_sm + n (elements of c_dtype) */
   long a_sg, a_sm, a_sk, b_sg, b_sk, b_sn, bias_sg, c_sg, c_sm;
   int a_dtype, b_dtype, bias_dtype;
   int G, M, N, K;
   float alpha;
   int store;        /* 0: C += result (C zero-filled by the caller; long contractions may be split, f32 atomics);
                        1: C = result, plain stores, the contraction is never split (deterministic) */
+  int c_dtype;      /* VQAF_F32; VQAF_BF16 is allowed with store = 1: the product leaves in the type its consumer
+                       wants (parameter gradients of a bf16 module) and no cast launch follows it */
 } vqaf_gemm_desc;
 int vqaf_gemm_f32_group(int n, const vqaf_gemm_desc* probs_host, vqaf_stream_t stream);
 

@@ -232,16 +232,25 @@ def test_fused_token_kernels_are_bit_identical_to_the_separate_launches(dev, dty
     c4.fill_(-3.0)
     descs = (_lib.GemmDesc * 4)(
         _lib.GemmDesc(ptr(a1), ptr(b1), ptr(bias1), ptr(c1), 0, 300, 1, 0, 130, 1, 0, 0, 130,
-                      dtype_code(a1), _lib.F32, _lib.F32, 1, 70, 130, 300, 0.5, 0),
+                      dtype_code(a1), _lib.F32, _lib.F32, 1, 70, 130, 300, 0.5, 0, _lib.F32),
         _lib.GemmDesc(ptr(a2), ptr(b2), None, ptr(c2), 0, 1, 48, 0, 96, 1, 0, 0, 96,
-                      _lib.F32, dtype_code(b2), _lib.F32, 1, 48, 96, 256, 1.0, 1),
+                      _lib.F32, dtype_code(b2), _lib.F32, 1, 48, 96, 256, 1.0, 1, _lib.F32),
         _lib.GemmDesc(ptr(a3), ptr(b3), None, ptr(c3), 33 * 64, 64, 1, 64 * 40, 40, 1, 0, 33 * 40, 40,
-                      _lib.F32, _lib.F32, _lib.F32, 4, 33, 40, 64, 2.0, 0),
+                      _lib.F32, _lib.F32, _lib.F32, 4, 33, 40, 64, 2.0, 0, _lib.F32),
         _lib.GemmDesc(ptr(ones), ptr(x4), None, ptr(c4), 0, 0, 0, 0, 200, 1, 0, 0, 200,
-                      _lib.F32, dtype_code(x4), _lib.F32, 1, 1, 200, 700, 1.0, 1))
+                      _lib.F32, dtype_code(x4), _lib.F32, 1, 1, 200, 700, 1.0, 1, _lib.F32))
     check(lib.vqaf_gemm_f32_group(4, ctypes.cast(descs, ctypes.c_void_p), st), "gemm group")
     want = (0.5 * a1.double() @ b1.double() + bias1.double(), a2.double().t() @ b2.double(),
             2.0 * torch.bmm(a3.double(), b3.double()), x4.double().sum(0))
     for got, w in zip((c1, c2, c3, c4), want):
         assert float((got.double() - w).abs().max()) < 2e-4 * max(1.0, float(w.abs().max()))
     assert lib.vqaf_gemm_f32_group(13, ctypes.cast(descs, ctypes.c_void_p), st) != 0
+    # a stored product may leave as bf16 (one rounding of the f32 result); a product added into its output may not
+    c5 = torch.full((4, 33, 40), 9.0, dtype=torch.bfloat16, device=dev)
+    d5 = (_lib.GemmDesc * 1)(_lib.GemmDesc(ptr(a3), ptr(b3), None, ptr(c5), 33 * 64, 64, 1, 64 * 40, 40, 1, 0, 33 * 40, 40,
+                                          _lib.F32, _lib.F32, _lib.F32, 4, 33, 40, 64, 2.0, 1, _lib.BF16))
+    check(lib.vqaf_gemm_f32_group(1, ctypes.cast(d5, ctypes.c_void_p), st), "gemm group bf16")
+    w5 = 2.0 * torch.bmm(a3.double(), b3.double())
+    assert float((c5.double() - w5).abs().max()) < 2.0 ** -8 * float(w5.abs().max())
+    d5[0].store = 0
+    assert lib.vqaf_gemm_f32_group(1, ctypes.cast(d5, ctypes.c_void_p), st) != 0

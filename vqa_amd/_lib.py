@@ -61,7 +61,7 @@ class GemmDesc(ctypes.Structure):
                 ("a_sg", c_long), ("a_sm", c_long), ("a_sk", c_long), ("b_sg", c_long), ("b_sk", c_long),
                 ("b_sn", c_long), ("bias_sg", c_long), ("c_sg", c_long), ("c_sm", c_long),
                 ("a_dtype", c_int), ("b_dtype", c_int), ("bias_dtype", c_int),
-                ("G", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("alpha", c_float), ("store", c_int)]
+                ("G", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("alpha", c_float), ("store", c_int), ("c_dtype", c_int)]
 
 
 class DenseFwdMod(ctypes.Structure):

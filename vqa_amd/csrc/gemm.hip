@@ -298,6 +298,7 @@ struct GemmProb {
   int splits, k_per_split, tiles_x, tiles_y;
   int wg_begin;  // first workgroup of this problem
   int store;     // C = result with plain stores (the contraction is then never split); else C += result (atomics)
+  int c_bf16;    // (store only) C holds bf16: the product leaves in its consumer's type, no cast launch after it
 };
 struct GemmGroupArgs {
   GemmProb p[GEMM_MAX_GROUP];
@@ -401,8 +402,12 @@ gemm_f32_group_kernel(GemmGroupArgs args) {
     const int gm = gm0 + (r & 3) + 8 * (r >> 2);
     if (gm < M && gn < N) {
       const float v = alpha * acc[r] + bias_v;
-      if (P.store) c0[(long)gm * P.c_sm] = v;
-      else atomicAdd(c0 + (long)gm * P.c_sm, v);
+      if (P.store) {
+        if (P.c_bf16) reinterpret_cast<bf16_t*>(P.C)[(long)g * P.c_sg + gn + (long)gm * P.c_sm] = f32_to_bf16(v);
+        else c0[(long)gm * P.c_sm] = v;
+      } else {
+        atomicAdd(c0 + (long)gm * P.c_sm, v);
+      }
     }
   }
 }
@@ -649,8 +654,10 @@ extern "C" int vqaf_gemm_f32_group(int n, const vqaf_gemm_desc* probs_host, vqaf
     VQAF_REQUIRE(vqaf_dtype_ok(d.a_dtype) && vqaf_dtype_ok(d.b_dtype) && (d.bias == nullptr || vqaf_dtype_ok(d.bias_dtype)),
                  VQAF_E_DTYPE);
     VQAF_REQUIRE(d.G > 0 && d.M > 0 && d.N > 0 && d.K > 0, VQAF_E_SHAPE);
+    // sums built with atomic adds are f32; a stored product may leave as bf16
+    VQAF_REQUIRE(d.c_dtype == VQAF_F32 || (d.c_dtype == VQAF_BF16 && d.store), VQAF_E_DTYPE);
     GemmProb& P = args.p[i];
-    P.A = d.A; P.Bm = d.Bm; P.bias = d.bias; P.C = d.C;
+    P.A = d.A; P.Bm = d.Bm; P.bias = d.bias; P.C = reinterpret_cast<float*>(d.C);
     P.a_sg = d.a_sg; P.a_sm = d.a_sm; P.a_sk = d.a_sk;
     P.b_sg = d.b_sg; P.b_sk = d.b_sk; P.b_sn = d.b_sn;
     P.bias_sg = d.bias_sg; P.c_sg = d.c_sg; P.c_sm = d.c_sm;
@@ -670,6 +677,7 @@ extern "C" int vqaf_gemm_f32_group(int n, const vqaf_gemm_desc* probs_host, vqaf
       while (splits < 16 && total_tiles * splits < 512 && d.K / (splits * 2) >= 2 * GK) splits *= 2;
     P.splits = splits;
     P.store = d.store != 0;
+    P.c_bf16 = d.c_dtype == VQAF_BF16;
     P.k_per_split = ((d.K + splits - 1) / splits + GK - 1) / GK * GK;
     P.wg_begin = wg;
     VQAF_REQUIRE(tiles * splits < (1l << 24), VQAF_E_SHAPE);

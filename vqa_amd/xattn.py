@@ -82,12 +82,17 @@ class _SingleQueryTokens(torch.autograd.Function):
                                 ctx.needs_input_grad[1])
 
 
-def _zeroed(dev, *shapes, with_flat=False):
+def _zeroed(dev, *shapes, with_flat=False, zero_first=None):
     """f32 tensors of the given shapes carved out of ONE zero-filled allocation (one fill launch): outputs of
     _gemm(..., into_zeros=True), which then adds into them instead of clearing each one with its own memset.
-    with_flat: also returns the allocation itself and the pieces' element offsets in it."""
+    with_flat: also returns the allocation itself and the pieces' element offsets in it.  zero_first = n: only
+    the first n pieces are cleared (the others are outputs that a product STORES)."""
     sizes = [(math.prod(sh) + 3) // 4 * 4 for sh in shapes]  # 16-byte aligned pieces
-    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    if zero_first is None or zero_first >= len(shapes):
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    else:
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        flat[:sum(sizes[:zero_first])].zero_()
     out, offs, o = [], [], 0
     for sh, n in zip(shapes, sizes):
         out.append(flat[o:o + math.prod(sh)].view(sh))
@@ -270,11 +275,11 @@ def _gemm_group(probs):
 
     arr = (_lib.GemmDesc * len(probs))()
     for i, (A, a_s, Bm, b_s, C, c_s, G, M, N, K, alpha, bias, bias_sg, store) in enumerate(probs):
-        assert C[0].dtype == torch.float32
+        assert C[0].dtype == torch.float32 or (store and C[0].dtype == torch.bfloat16)
         arr[i] = _lib.GemmDesc(addr(A), addr(Bm), addr(bias) if bias is not None else None, addr(C),
                                a_s[0], a_s[1], a_s[2], b_s[0], b_s[1], b_s[2], bias_sg, c_s[0], c_s[1],
                                code(A[0]), code(Bm[0]), code(bias[0]) if bias is not None else _lib.F32,
-                               G, M, N, K, float(alpha), int(store))
+                               G, M, N, K, float(alpha), int(store), code(C[0]))
     import ctypes
     check(load().vqaf_gemm_f32_group(len(probs), ctypes.cast(arr, ctypes.c_void_p), stream_ptr(probs[0][4][0].device)),
           "vqaf_gemm_f32_group")
@@ -287,6 +292,12 @@ class _DenseCoAttention(torch.autograd.Function):
     softmax + weighted-token-sum launch, one launch per (B,E)-sized projection; the backward likewise (the
     softmax backward, the folded-query gradient and the token gradient share one pass over the tokens).
     Same arithmetic as _DenseSingleQuery per branch."""
+
+    @staticmethod
+    def _bwd_zero_words(nb, B, E):
+        """f32 words of the block that the backward's split products are ADDED into: d_attn and d_qp (nb, B, E each)
+        and the in-projection bias gradients (nb, 3E; the key third is an exact zero that nothing writes)."""
+        return 2 * nb * B * E + nb * 3 * E
 
     @staticmethod
     def forward(ctx, H, out_dtype, *flat):
@@ -320,8 +331,11 @@ class _DenseCoAttention(torch.autograd.Function):
         fm = (_lib.DenseFwdMod * nb)(*[_lib.DenseFwdMod(ptr(seq_c[i]), ptr(s[i]), ptr(p[i]), ptr(z[i]), Ns[i])
                                        for i in range(nb)])
         # (the same launch clears attn and out, which the two projections below build with atomic adds)
-        zbuf = torch.empty(2 * nb * B * E, **f32)
-        attn, out = zbuf[:nb * B * E].view(nb, B, E), zbuf[nb * B * E:].view(B, nb * E)
+        # ... and, when a backward will follow, the block its products are added into: no fill launch there
+        wants_grad = any(ctx.needs_input_grad)
+        zbuf = torch.empty(2 * nb * B * E + (_DenseCoAttention._bwd_zero_words(nb, B, E) if wants_grad else 0), **f32)
+        attn, out = zbuf[:nb * B * E].view(nb, B, E), zbuf[nb * B * E:2 * nb * B * E].view(B, nb * E)
+        ctx.bwd_zero = zbuf[2 * nb * B * E:] if wants_grad else None
         check(lib.vqaf_softmax_wsum_multi(ctypes.cast(fm, ctypes.c_void_p), nb, B, E, H, dtype_code(seq_c[0]),
                                           ptr(zbuf), zbuf.numel(), st), "vqaf_softmax_wsum_multi")
         # attn_i[:, head h] = z_i[:,h,:] Wv_i[head h, :]^T + bv_i[head h]
@@ -360,9 +374,25 @@ class _DenseCoAttention(torch.autograd.Function):
             g = g.float()
         scale = 1.0 / math.sqrt(dh)
         rng = range(nb)
-        # internal products first, then everything that is handed back (one block, so that one cast serves it)
-        shapes = ((nb, B, E), (nb, B, H, E), (nb, B, E), (nb, B, E), (nb, 3 * E, E), (nb, 3 * E), (nb, E, E), (nb, E))
-        (d_attn, t, d_qp, d_q, d_win, d_bin, d_wout, d_bout), zflat, zoffs = _zeroed(dev, *shapes, with_flat=True)
+        # Everything handed back is STORED by the product that computes it, in the type its consumer wants (the
+        # inputs' common dtype; f32 when they differ, cast per tensor at the end): the weight gradients and the bias
+        # gradients contract over the batch only (a few fetch stages), the query gradient over the width (16 stages,
+        # beside the others in its launch).  Nothing of it needs clearing, no atomics, no cast launch.  What is built
+        # with atomic adds over split contractions (d_attn, d_qp) and the key-bias zeros sit in one small block that
+        # the forward's clearing launch already cleared; t, the gradient at the per-head token sums, is stored too.
+        want = {d for dts, n in zip(ctx.dtypes, need) for d, nd in zip(dts, (n[0], n[2], n[3], n[4], n[5])) if nd}
+        rd = next(iter(want)) if len(want) == 1 and next(iter(want)) in (torch.float32, torch.bfloat16) else torch.float32
+        zb = ctx.bwd_zero
+        ctx.bwd_zero = None  # (a second backward through the same graph clears a block of its own)
+        if zb is None:
+            zb = torch.zeros(_DenseCoAttention._bwd_zero_words(nb, B, E), **f32)
+        n1 = nb * B * E
+        d_attn, d_qp = zb[:n1].view(nb, B, E), zb[n1:2 * n1].view(nb, B, E)
+        d_bin = zb[2 * n1:].view(rd)[:nb * 3 * E].view(nb, 3 * E)
+        ret = dict(dtype=rd, device=dev)
+        d_q, d_bout = torch.empty(nb, B, E, **ret), torch.empty(nb, E, **ret)
+        d_win, d_wout = torch.empty(nb, 3 * E, E, **ret), torch.empty(nb, E, E, **ret)
+        t = torch.empty(nb, B, H, E, **f32)
         # through the output projection: d_attn_i = g[:, i*E:(i+1)*E] Wout_i
         _gemm_sets([(g, i * E) for i in rng], (0, nb * E, 1), [(w_out[i], 0) for i in rng], (0, E, 1),
                    [(d_attn[i], 0) for i in rng], (0, E), 1, B, E, E)
@@ -373,16 +403,19 @@ class _DenseCoAttention(torch.autograd.Function):
         for i in rng:
             # through the value projection: t_i[:,h,:] = d_attn_i[:, head h] Wv_i[head h, :]
             group.append(_prob((d_attn[i], 0), (dh, E, 1), (w_in[i], 2 * E * E), (dh * E, E, 1), (t[i], 0), (E, H * E),
-                               H, B, E, dh))
+                               H, B, E, dh, store=True))
             if need_par:
                 # dWout_i = g_i^T attn_i;  dWv_i[head h rows] = d_attn_i[:, head h]^T z_i[:,h,:]
-                group.append(_prob((g, i * E), (0, 1, nb * E), (attn[i], 0), (0, E, 1), (d_wout[i], 0), (0, E), 1, E, E, B))
+                group.append(_prob((g, i * E), (0, 1, nb * E), (attn[i], 0), (0, E, 1), (d_wout[i], 0), (0, E), 1, E, E, B,
+                                   store=True))
                 group.append(_prob((d_attn[i], 0), (dh, 1, E), (z[i], 0), (E, H * E, 1), (d_win[i], 2 * E * E),
-                                   (dh * E, E), H, dh, E, B))
+                                   (dh * E, E), H, dh, E, B, store=True))
                 # bias gradients = column sums = products with a row of ones: of g (output bias) and of d_attn (value
                 # bias); the key bias shifts every score of a head alike and keeps its exact zero
-                group.append(_prob(ones, (0, 0, 0), (g, i * E), (0, nb * E, 1), (d_bout[i], 0), (0, E), 1, 1, E, B))
-                group.append(_prob(ones, (0, 0, 0), (d_attn[i], 0), (0, E, 1), (d_bin[i], 2 * E), (0, E), 1, 1, E, B))
+                group.append(_prob(ones, (0, 0, 0), (g, i * E), (0, nb * E, 1), (d_bout[i], 0), (0, E), 1, 1, E, B,
+                                   store=True))
+                group.append(_prob(ones, (0, 0, 0), (d_attn[i], 0), (0, E, 1), (d_bin[i], 2 * E), (0, E), 1, 1, E, B,
+                                   store=True))
         _gemm_group(group)
         # through the token passes
         dp = [torch.empty(B, n, H, **f32) for n in Ns]
@@ -406,26 +439,21 @@ class _DenseCoAttention(torch.autograd.Function):
                 if need_par:
                     # dWk_i[head h rows] = qp_i[:, head h]^T du_i[:,h,:] / sqrt(dh)
                     group.append(_prob((qp[i], 0), (dh, 1, E), (du[i], 0), (E, H * E, 1), (d_win[i], E * E), (dh * E, E),
-                                       H, dh, E, B, alpha=scale))
+                                       H, dh, E, B, alpha=scale, store=True))
             _gemm_group(group)
             group = []
             for i in rng:
                 if need_par:
                     # dWq_i = d_qp_i^T query_i; the query bias gradient = column sums of d_qp
-                    group.append(_prob((d_qp[i], 0), (0, 1, E), (q_c[i], 0), (0, E, 1), (d_win[i], 0), (0, E), 1, E, E, B))
-                    group.append(_prob(ones, (0, 0, 0), (d_qp[i], 0), (0, E, 1), (d_bin[i], 0), (0, E), 1, 1, E, B))
+                    group.append(_prob((d_qp[i], 0), (0, 1, E), (q_c[i], 0), (0, E, 1), (d_win[i], 0), (0, E), 1, E, E, B,
+                                       store=True))
+                    group.append(_prob(ones, (0, 0, 0), (d_qp[i], 0), (0, E, 1), (d_bin[i], 0), (0, E), 1, 1, E, B,
+                                       store=True))
                 if need_q:
-                    group.append(_prob((d_qp[i], 0), (0, E, 1), (w_in[i], 0), (0, E, 1), (d_q[i], 0), (0, E), 1, B, E, E))
+                    group.append(_prob((d_qp[i], 0), (0, E, 1), (w_in[i], 0), (0, E, 1), (d_q[i], 0), (0, E), 1, B, E, E,
+                                       store=True))
             if group:
                 _gemm_group(group)
-        # hand back in the inputs' dtypes: when they all share one (the usual bf16 module), ONE cast of the block
-        # of returned products serves every gradient
-        want = {d for dts, n in zip(ctx.dtypes, need) for d, nd in zip(dts, (n[0], n[2], n[3], n[4], n[5])) if nd}
-        if len(want) == 1 and next(iter(want)) != torch.float32:
-            lo = zoffs[3]
-            block = zflat[lo:].to(next(iter(want)))
-            d_q, d_win, d_bin, d_wout, d_bout = (block[o - lo:o - lo + math.prod(sh)].view(sh)
-                                                 for o, sh in zip(zoffs[3:], shapes[3:]))
         grads = [None, None]
         for i in rng:
             qd, wid, bid, wod, bod = ctx.dtypes[i]
