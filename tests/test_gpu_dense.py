@@ -151,6 +151,66 @@ def test_batched_branches_equal_the_per_branch_launches(dev, B, Nv, Nq, dtype, n
         assert float(pa[n][512:1024].abs().max()) == 0.0
 
 
+def test_batched_backward_with_frozen_parameters_and_a_second_backward(dev):
+    """The launch-sharing backward when only some gradients are asked for -- parameters frozen (query and token
+    gradients only), tokens frozen (parameter gradients only) -- and when it runs twice through one graph
+    (retain_graph): the block it adds into is cleared by the forward for the first backward only, so the second
+    must clear its own.  Every variant equals the corresponding gradients of the full run."""
+    from vqa_amd.fusion import CoAttention
+    torch.manual_seed(4)
+    dtype, B, Nv, Nq = torch.bfloat16, 7, 120, 30
+    m = CoAttention(embed_dim=512, num_heads=8, use_pruning=False).to(dev).to(dtype)
+    gen = torch.Generator(device=dev).manual_seed(8)
+    base = [torch.randn(*sh, device=dev, generator=gen).to(dtype) for sh in ((B, Nv, 512), (B, 512), (B, Nq, 512), (B, 512))]
+    cot = torch.randn(B, 1024, device=dev, generator=gen)
+
+    def run(req_inputs, req_params, twice=False):
+        for p_ in m.parameters():
+            p_.requires_grad_(req_params)
+        m.zero_grad(set_to_none=True)
+        ins = [t.clone().requires_grad_(req_inputs) for t in base]
+        loss = (m(*ins).float() * cot).sum()
+        if twice:
+            loss.backward(retain_graph=True)
+            first = ([t.grad.clone() for t in ins], {n: p_.grad.clone() for n, p_ in m.named_parameters()})
+            for t in ins:
+                t.grad = None
+            m.zero_grad(set_to_none=True)
+            loss.backward()
+            second = ([t.grad for t in ins], {n: p_.grad for n, p_ in m.named_parameters()})
+            # (not bit for bit: d_attn and d_qp are sums over split contractions, whose atomic order is not fixed)
+            for a, b in zip(first[0], second[0]):
+                scale = float(a.float().abs().max()) + 1e-30
+                assert float((a.float() - b.float()).abs().max()) <= 1e-2 * scale
+            for n in first[1]:
+                scale = float(first[1][n].float().abs().max()) + 1e-30
+                assert float((first[1][n].float() - second[1][n].float()).abs().max()) <= 1e-2 * scale, n
+        else:
+            loss.backward()
+        return ([None if t.grad is None else t.grad.float() for t in ins],
+                {n: None if p_.grad is None else p_.grad.float() for n, p_ in m.named_parameters()})
+
+    full_i, full_p = run(True, True)
+    twice_i, twice_p = run(True, True, twice=True)
+    frozen_i, frozen_p = run(True, False)
+    only_p_i, only_p = run(False, True)
+    for p_ in m.parameters():
+        p_.requires_grad_(True)
+
+    def close(a, b, what):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 1e-2 * scale, what
+
+    for i in range(4):
+        close(twice_i[i], full_i[i], f"second backward, input {i}")
+        close(frozen_i[i], full_i[i], f"frozen parameters, input {i}")
+        assert only_p_i[i] is None
+    for n in full_p:
+        close(twice_p[n], full_p[n], f"second backward, {n}")
+        close(only_p[n], full_p[n], f"frozen inputs, {n}")
+        assert frozen_p[n] is None
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("H", [8, 4, 3])
 def test_fused_token_kernels_are_bit_identical_to_the_separate_launches(dev, dtype, H):
