@@ -311,3 +311,18 @@ def test_vision_wrappers_have_the_reference_surface(tmp_path):
     d = SwinConfig()
     assert (d.embed_dim, tuple(d.depths), tuple(d.num_heads), d.window_size, d.hidden_size) == \
         (96, (2, 2, 6, 2), (3, 6, 12, 24), 7, 768)
+
+
+def test_model_registry_resolves_the_reference_configuration_names():
+    """utils/util.py:50-66: every Vision / Text name of the reference's registry resolves, each class takes the
+    keyword VQAModel constructs it with, and the model table holds VQAModel."""
+    import inspect
+    from vqa_amd import model
+    vis, txt, models = model.get_model_registry()
+    assert {"CNN", "ResNet50", "SwinTransformer"} <= set(vis)
+    assert set(txt) == {"Bert", "RoBerta", "BertQLoRA", "RoBertaQLoRA"}
+    assert models == {"VQAModel": model.VQAModel}
+    for cls in vis.values():
+        assert "out_features" in inspect.signature(cls.__init__).parameters
+    for cls in txt.values():
+        assert "hidden_dim" in inspect.signature(cls.__init__).parameters

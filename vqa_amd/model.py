@@ -102,3 +102,15 @@ def load_weights(model: nn.Module, state_dict: dict) -> nn.Module:
     renamed = {k.replace("classifier._module.", "classifier."): v for k, v in state_dict.items()}
     model.load_state_dict(renamed, strict=False)
     return model
+
+
+def get_model_registry():
+    """The three name -> class tables of the reference (utils/util.py:47-68), filled with this package's
+    classes: what a configuration file's `Vision:`, `Text:` and `model:` entries resolve to.  `ViT` is an
+    addition (the reference has no plain ViT wrapper); `VQAModel_IB`, the information-bottleneck variant that
+    the reference excludes from DP-SGD training (train.py:177-178), is not built."""
+    from . import encoders, vision
+    vision_models = dict(vision.get_vision_registry(), ViT=encoders.ViT)
+    text_models = {"Bert": encoders.Bert, "RoBerta": encoders.RoBerta, "BertQLoRA": encoders.BertQLoRA,
+                   "RoBertaQLoRA": encoders.RoBertaQLoRA}
+    return vision_models, text_models, {"VQAModel": VQAModel}
